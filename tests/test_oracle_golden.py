@@ -1,0 +1,100 @@
+"""Pin the CPU oracle (oracle/p2i_oracle.py) to golden vectors captured from the genuine
+reference by tests/golden/make_golden.py.  CPU only."""
+import numpy as np
+import torch
+
+from conftest import rel_err
+from oracle import p2i_oracle as O
+from p2igan_bench.utils import seeded
+
+TOL = 1e-4   # north_star: 1e-4 rel fp32
+
+
+def _batch32():
+    h = w = 32
+    m0 = seeded.gauge_mask(h, w, 20)
+    m1 = seeded.block_mask(h, w, 4)
+    f0, k0, mk0 = seeded.synthetic_batch(1, 16, h, w, m0, seed=2024)
+    f1, k1, mk1 = seeded.synthetic_batch(1, 16, h, w, m1, seed=3024)
+    return torch.cat([f0, f1]), torch.cat([k0, k1]), torch.cat([mk0, mk1])
+
+
+def test_idw_matches_reference(golden):
+    g = golden("idw.npz")
+    for name in ("gauge", "few", "lattice"):
+        mask = torch.from_numpy(g[name + "_mask"])
+        mk = mask.reshape(1, 32, 32).expand(16, 32, 32)
+        tz, ty, tx, pts = O.mask_points(mk)
+        out = O.idw_3d_knn(pts, torch.from_numpy(g[name + "_vals"]), (16, 32, 32))
+        assert rel_err(out.numpy(), g[name + "_out"]) < 1e-6, name
+
+
+def test_train_steps_match_reference(golden):
+    g = golden("e2e_32.npz")
+    frames, masked, masks = _batch32()
+    st = O.TrainState(seeded.seeded_generator_state(32, 32), seeded.seeded_discriminator_state(),
+                      {"k1_weight": 0.05, "adversarial_weight": 0.01, "gan_loss": "hinge"},
+                      {"lr": 1e-4, "beta1": 0.0, "beta2": 0.99})
+    r = st.step(frames, masked, masks, keep_grads=True)
+    assert rel_err(r["preds"].numpy(), g["preds"]) < TOL
+    assert rel_err(r["logits_fake"].numpy(), g["logits_fake"]) < TOL
+    assert rel_err(r["logits_real"].numpy(), g["logits_real"]) < TOL
+    for k in ("loss_g", "loss_d", "adv", "pool", "reg"):
+        assert abs(r[k] - float(g[k])) <= TOL * abs(float(g[k])), k
+    for k in g.files:
+        if k.startswith("ggradnorm/"):
+            n = k.split("/", 1)[1]
+            assert abs(float(r["ggrads"][n].norm()) - float(g[k])) <= 1e-3 * float(g[k]) + 1e-7, k
+        if k.startswith("dgradnorm/"):
+            n = k.split("/", 1)[1]
+            assert abs(float(r["dgrads"][n].norm()) - float(g[k])) <= 1e-3 * float(g[k]) + 1e-7, k
+        if k.startswith("ggrad/"):
+            assert rel_err(r["ggrads"][k.split("/", 1)[1]].numpy(), g[k]) < 1e-3, k
+        if k.startswith("dgrad/"):
+            assert rel_err(r["dgrads"][k.split("/", 1)[1]].numpy(), g[k]) < 1e-3, k
+    assert r["dgrads"]["alpha3d"] is None      # alpha3d never receives a gradient (p2igan.py:145,170)
+    for k in g.files:
+        if k.startswith("g1sum/"):
+            n = k.split("/", 1)[1]
+            assert abs(float(st.gp[n].double().sum()) - float(g[k])) <= 1e-5 * max(1.0, abs(float(g[k]))), k
+        if k.startswith("d1sum/"):
+            n = k.split("/", 1)[1]
+            assert abs(float(st.dp[n].double().sum()) - float(g[k])) <= 1e-5 * max(1.0, abs(float(g[k]))), k
+    assert rel_err(st.dp["d3d.0.weight_u"].numpy(), g["d1/d3d.0.weight_u"]) < 1e-5
+    r = st.step(frames, masked, masks)
+    assert abs(r["loss_g"] - float(g["loss_g_step1"])) < 1e-3 * abs(float(g["loss_g_step1"]))
+    r = st.step(frames, masked, masks)
+    assert abs(r["loss_g"] - float(g["loss_g_step2"])) < 1e-3 * abs(float(g["loss_g_step2"]))
+    assert abs(r["loss_d"] - float(g["loss_d_step2"])) < 1e-3 * abs(float(g["loss_d_step2"]))
+    assert rel_err(st.gp["Convsin.0.main.0.W"].numpy(), g["g3/Convsin.0.main.0.W"]) < 1e-3
+    assert rel_err(st.dp["d2d.2.bias"].numpy(), g["d3/d2d.2.bias"]) < 1e-3
+
+
+def test_infer_event_matches_reference(golden):
+    g = golden("infer_32.npz")
+    h = w = 32
+    gp = seeded.seeded_generator_state(h, w)
+    m = seeded.gauge_mask(h, w, 24, seed=7)
+    L = 40
+    ev = seeded.synthetic_event(L, h, w, seed=99).float() / 255.0
+    frames = ev.reshape(1, L, 1, h, w)
+    masks = m.reshape(1, 1, 1, h, w).expand(1, L, 1, h, w).contiguous()
+    comp = O.infer_event(gp, frames * masks, masks)
+    assert rel_err(comp.numpy(), g["comp"]) < TOL
+    with torch.no_grad():
+        z = O.generator_forward(gp, frames[:, :16] * 0, masks[:, :16] * 0)
+        logits = O.discriminator_forward(seeded.seeded_discriminator_state(), frames[:, :16], training=False)
+    assert rel_err(z.numpy(), g["empty"]) < TOL
+    assert rel_err(logits.numpy(), g["logits_eval"]) < TOL
+
+
+def test_generator_128_matches_reference(golden):
+    g = golden("g_128.npz")
+    gp = seeded.seeded_generator_state(128, 128)
+    frames, masked, masks = seeded.synthetic_batch(1, 16, 128, 128, seeded.gauge_mask(128, 128, 79))
+    taps = {}
+    with torch.no_grad():
+        preds = O.generator_forward(gp, masked, masks, taps)
+    assert rel_err(taps["idw"].numpy()[0, :, ::3, ::3], g["idw_s3"]) < 1e-6
+    assert rel_err(preds.numpy()[0, :, 0, ::3, ::3], g["preds_s3"]) < TOL
+    assert abs(float(preds.double().sum()) - float(g["preds_sum"])) < 1e-4 * float(g["preds_abs_sum"])
