@@ -1,0 +1,163 @@
+/* p2i_hip.h — C ABI of libp2i_hip.so, the MI355X (gfx950) kernel library under the P2I-GAN hot path.
+ *
+ * The reference (NTU-CompHydroMet-Lab/P2I-GAN-benchmark) is pure Python on PyTorch: the
+ * arithmetic of its hot path is reached through ATen call sites (F.conv2d, nn.Conv3d, cdist,
+ * topk, max_pool2d, Upsample, spectral_norm, kl_div, Adam).  Each entry point below replaces one
+ * group of those call sites; the file:line next to it is the reference code it stands in for
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous fp32 (or int32 where stated); the caller
+ *    (PyTorch) owns all memory including workspaces; the library never allocates or frees;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*), never syncs;
+ *  - return value: 0 on success, negative P2I_E* on a rejected argument, positive = hipError_t
+ *    of a failed launch.  Nothing throws across the ABI;
+ *  - activations are NC(T)HW; a 2-D tensor is the T == 1 case of the 5-D one.
+ */
+#ifndef P2I_HIP_H
+#define P2I_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2I_OK 0
+#define P2I_EINVAL (-1)   /* bad shape / unsupported configuration */
+#define P2I_ELDS (-2)     /* tile configuration does not fit LDS */
+
+/* activation codes shared by the conv epilogue and its backward prologue */
+#define P2I_ACT_NONE 0
+#define P2I_ACT_RELU 1
+#define P2I_ACT_LEAKY 2   /* negative slope 0.2 (p2igan.py:122-139) */
+#define P2I_ACT_TANH 3
+
+int p2i_abi_version(void);
+const char* p2i_last_error(void);
+
+/* ------------------------------------------------------------------ convolution engine
+ * Replaces F.conv2d / nn.Conv3d forward + convolution_backward (deconv_pytorch.py:103-109,
+ * layer.py:390,402-407, p2igan.py:120-142).  Weights are consumed in PACKED form
+ * Wp[tap][k_channel][m_channel_padded] (m padded to a multiple of 32, produced by the
+ * p2i_*_pack / p2i_doconv_fold entry points), so that the MFMA A-operand rows are contiguous.
+ *
+ * p2i_conv_fwd :  y = act(conv(x, W) + bias) + residual
+ * p2i_conv_dgrad: dx = conv_transpose(dy * act'(y), W)      (Wd = pack with roles swapped)
+ * p2i_conv_wgrad: dWp[tap][cin][cout_pad] += sum_pixels x * (dy * act'(y))   (atomic fp32 adds;
+ *                 caller zeroes dWp), db[cout] += sum dy*act'(y) when db != NULL.
+ * dims: x (B,Cin,Ti,Hi,Wi), y (B,Cout,To,Ho,Wo); kernel (kt,kh,kw); stride (st,sh,sw);
+ * padding (pt,ph,pw).  bias / residual / y_act may be NULL.
+ */
+typedef struct {
+  int B, Cin, Cout;
+  int Ti, Hi, Wi;
+  int To, Ho, Wo;
+  int kt, kh, kw;
+  int st, sh, sw;
+  int pt, ph, pw;
+} p2i_conv_desc;
+
+int p2i_conv_fwd(const p2i_conv_desc* d, const float* x, const float* wp, const float* bias,
+                 const float* residual, float* y, int act, void* stream);
+int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const float* y_act, int act,
+                   const float* wp_d, float* dx, void* stream);
+int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, const float* y_act,
+                   int act, float* dwp, float* dbias, void* stream);
+
+/* ------------------------------------------------------------------ weight preparation
+ * p2i_doconv_fold_fwd: DoW = einsum('ims,ois->oim', D + D_diag, W.reshape(O/g, I, 9)) with the
+ *   reference's memory reinterpretation to (O, I/g, 3, 3) (deconv_pytorch.py:111-127), written
+ *   densely (zeros outside the group) in both packed layouts: wp_f[9][I][Opad] for p2i_conv_fwd
+ *   and wp_d[9][O][Ipad] for p2i_conv_dgrad.  ksz==1: DoW = W.reshape (no D).  `identity_rep`>0
+ *   adds the `+ x.repeat_interleave(rep, dim=1)` skip of p2igan.py:79 as a centre-tap identity.
+ * p2i_doconv_fold_bwd: dW, dD from the packed weight gradient produced by p2i_conv_wgrad.
+ */
+int p2i_doconv_fold_fwd(const float* W, const float* D, const float* D_diag, int O, int I, int groups,
+                        int ksz, int identity_rep, float* wp_f, float* wp_d, void* stream);
+int p2i_doconv_fold_bwd(const float* dwp_f, const float* W, const float* D, const float* D_diag,
+                        int O, int I, int groups, int ksz, float* dW, float* dD, void* stream);
+
+/* Plain (O, I, ntaps) weights <-> packed.  scale_ptr (device scalar, may be NULL) divides: used
+ * for the spectral-norm weight = weight_orig / sigma. */
+int p2i_weight_pack(const float* w, int O, int I, int ntaps, const float* inv_div_ptr,
+                    float* wp_f, float* wp_d, void* stream);
+/* dw[o][i][tap] = dwp_f[tap][i][o] / sigma  - (sum(dwp_f .* w)/sigma^2) * u[o] * v[i*ntaps+tap]
+ * (gradient through torch.nn.utils.spectral_norm's `weight / sigma`); sigma_ptr NULL => plain unpack. */
+int p2i_weight_unpack_grad(const float* dwp_f, int O, int I, int ntaps, const float* w_orig,
+                           const float* sigma_ptr, const float* u, const float* v, float* scratch,
+                           float* dw, void* stream);
+
+/* ------------------------------------------------------------------ spectral norm
+ * One power iteration of torch.nn.utils.spectral_norm (call sites layer.py:402-407,
+ * p2igan.py:141): v <- normalize(W^T u), u <- normalize(W v), sigma = u^T W v, eps 1e-12.
+ * training==0: sigma only from the stored u, v.  W is (O, K) row-major.  scratch >= O + K + 4 floats.
+ */
+int p2i_spectral_norm(const float* w, int O, int K, float* u, float* v, int training, float* sigma,
+                      float* scratch, void* stream);
+
+/* ------------------------------------------------------------------ generator glue
+ * AttentionBlock x2 (layer.py:296-304, 318-322): per pixel relu(x + x*(Wx+b)) over the T=16 vector. */
+int p2i_attn_fwd(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                 float* out, int B, int T, int HW, void* stream);
+int p2i_attn_bwd(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                 const float* dout, float* dw0, float* db0, float* dw1, float* db1,
+                 int B, int T, int HW, void* stream);
+
+/* Gauge-point IDW (layer.py:324-361 + 259-293 + 246-256): nonzero(mask>0) in (t,y,x) order,
+ * 4-NN by torch.cdist's fp32 formula (|a|^2+|b|^2-2ab as an fma chain), torch.topk's
+ * partial-sort selection, w = 1/(d+tau)^2 normalised (+1e-12).  grid_[xyz] are the
+ * torch.linspace(0,1,n) tables.  Work buffers (caller-allocated):
+ *   pt_pos  int32 [B*Q]  flat (t,y,x) index of each point;  pt_count int32 [B] ; frame_count int32[B*T]
+ *   sel_idx int32 [B*Q*4], sel_w float [B*Q*4]  (saved for backward)
+ * Empty mask => zeros (layer.py:330-332). 0 < N < 4 is an error in the reference (topk k>N);
+ * here the output is NaN-free but unspecified and p2i_idw_status reports it. */
+int p2i_idw_fwd(const float* vals_src, const float* mask, const float* grid_x, const float* grid_y,
+                const float* grid_z, float* out, int32_t* pt_pos, int32_t* pt_count, int32_t* frame_count,
+                float* pt_xyzn, int32_t* sel_idx, float* sel_w, int B, int T, int H, int W, float tau,
+                void* stream);
+int p2i_idw_bwd(const float* dout, const int32_t* pt_pos, const int32_t* sel_idx, const float* sel_w,
+                float* dvals_src, int B, int T, int H, int W, void* stream);
+
+/* DownsampleDuplicateChannels (layer.py:205-214): 2x2 max-pool then duplicate every channel. */
+int p2i_pooldup_fwd(const float* x, float* y, int B, int C, int H, int W, void* stream);
+int p2i_pooldup_bwd(const float* x, const float* dy, float* dx, int B, int C, int H, int W, void* stream);
+
+/* UPPos front half (layer.py:392-396): u = bilinear_x2(x, align_corners=True) * 2*sigmoid(pos). */
+int p2i_upmod_fwd(const float* x, const float* pos, float* u, int B, int C, int S, int S2w /*in W*/, void* stream);
+int p2i_upmod_bwd(const float* x, const float* pos, const float* du, float* dx, float* dpos,
+                  int B, int C, int S, int S2w, void* stream);
+
+/* ------------------------------------------------------------------ discriminator tail
+ * p2igan.py:165-173: mean over T' of out3d, bilinear (align_corners=False) to out2d's size,
+ * fused = sigmoid(alpha2d)*out2d + that. */
+int p2i_dtail_fwd(const float* out2d, const float* out3d, const float* alpha2d, float* fused,
+                  int B, int H2, int W2, int T3, int H3, int W3, void* stream);
+int p2i_dtail_bwd(const float* out2d, const float* alpha2d, const float* dfused, float* dout2d,
+                  float* dout3d, float* dalpha2d, int B, int H2, int W2, int T3, int H3, int W3, void* stream);
+
+/* ------------------------------------------------------------------ losses
+ * ReconstructionLoss (losses.py:38-48,56-85): out[0]=pool (weighted L1), out[1]=reg (KL of
+ * temporal-difference softmaxes, batchmean), out[2]=pool+k1*reg; dpred = d out[2]/d pred.
+ * scratch >= B*(T-1)*HW + 4096 floats. */
+int p2i_recloss(const float* pred, const float* target, float k1_alpha, float* out3, float* dpred,
+                float* scratch, int B, int T, int HW, void* stream);
+/* Hinge / lsgan losses (losses.py:210-226) with gradients.  mode: 0 = discriminator
+ * (0.5*(L(real)+L(fake)), train.py:266-283), 1 = generator (-mean * weight, train.py:301-308). */
+int p2i_gan_loss(const float* logits_a, const float* logits_b, int n, int loss_type, int mode,
+                 float weight, float real_label, float fake_label, float* loss, float* dlogits_a,
+                 float* dlogits_b, void* stream);
+
+/* ------------------------------------------------------------------ optimiser
+ * torch.optim.Adam step on flat fp32 buffers (train.py:125-136): no weight decay, no amsgrad. */
+int p2i_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+             float beta2, float eps, int step, void* stream);
+
+/* small helpers on the same stream */
+int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stream);        /* y += a*x */
+int p2i_bias_grad(const float* dy, const float* y_act, int act, float* db, int B, int C, int64_t inner, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2I_HIP_H */

@@ -1,0 +1,422 @@
+// HBM-bound glue kernels of the P2I-GAN hot path: AttentionBlock (layer.py:296-304),
+// DownsampleDuplicateChannels (layer.py:205-214), UPPos upsample+modulation (layer.py:392-396),
+// discriminator tail (p2igan.py:165-173), bias gradient, axpy, Adam (train.py:125-136).
+#include "common.h"
+
+namespace p2i {
+
+// ------------------------------------------------------------------ AttentionBlock x2
+// x (B,T,HW): thread = one pixel, the T=16 vector lives in registers.
+template <int T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w0,
+                                                       const float* __restrict__ b0, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, float* out, int B, int HW) {
+  __shared__ float sw[2][T * T + T];
+  for (int i = threadIdx.x; i < T * T; i += blockDim.x) { sw[0][i] = w0[i]; sw[1][i] = w1[i]; }
+  for (int i = threadIdx.x; i < T; i += blockDim.x) { sw[0][T * T + i] = b0[i]; sw[1][T * T + i] = b1[i]; }
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (p >= HW) return;
+  float h[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) h[t] = x[((size_t)b * T + t) * HW + p];
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    float n[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      float g = sw[l][T * T + i];
+#pragma unroll
+      for (int j = 0; j < T; ++j) g += sw[l][i * T + j] * h[j];
+      const float a = h[i] + h[i] * g;
+      n[i] = a > 0.f ? a : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i) h[i] = n[i];
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) out[((size_t)b * T + t) * HW + p] = h[t];
+}
+
+// parameter gradients only (the block's input is data).  Pixels whose dout is all zero (every
+// non-gauge pixel: the IDW scatter touches gauge voxels only) are skipped.
+template <int T>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w0,
+                                                       const float* __restrict__ b0, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const float* __restrict__ dout,
+                                                       float* dw0, float* db0, float* dw1, float* db1, int B, int HW) {
+  __shared__ float sw[2][T * T + T];
+  for (int i = threadIdx.x; i < T * T; i += blockDim.x) { sw[0][i] = w0[i]; sw[1][i] = w1[i]; }
+  for (int i = threadIdx.x; i < T; i += blockDim.x) { sw[0][T * T + i] = b0[i]; sw[1][T * T + i] = b1[i]; }
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (p >= HW) return;
+  float go[T];
+  bool any = false;
+#pragma unroll
+  for (int t = 0; t < T; ++t) { go[t] = dout[((size_t)b * T + t) * HW + p]; any |= (go[t] != 0.f); }
+  if (!any) return;
+  float h0[T], g1[T], a1[T], h1[T], g2[T], a2[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) h0[t] = x[((size_t)b * T + t) * HW + p];
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    float g = sw[0][T * T + i];
+#pragma unroll
+    for (int j = 0; j < T; ++j) g += sw[0][i * T + j] * h0[j];
+    g1[i] = g; a1[i] = h0[i] + h0[i] * g; h1[i] = a1[i] > 0.f ? a1[i] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    float g = sw[1][T * T + i];
+#pragma unroll
+    for (int j = 0; j < T; ++j) g += sw[1][i * T + j] * h1[j];
+    g2[i] = g; a2[i] = h1[i] + h1[i] * g;
+  }
+  float dg2[T], dh1[T], dg1[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const float da2 = a2[i] > 0.f ? go[i] : 0.f;
+    dg2[i] = da2 * h1[i];
+    dh1[i] = da2 * (1.f + g2[i]);
+  }
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < T; ++i) acc += sw[1][i * T + j] * dg2[i];
+    dh1[j] += acc;
+  }
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const float da1 = a1[i] > 0.f ? dh1[i] : 0.f;
+    dg1[i] = da1 * h0[i];
+  }
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    if (dg2[i] != 0.f) {
+      atomicAdd(db1 + i, dg2[i]);
+#pragma unroll
+      for (int j = 0; j < T; ++j) atomicAdd(dw1 + i * T + j, dg2[i] * h1[j]);
+    }
+    if (dg1[i] != 0.f) {
+      atomicAdd(db0 + i, dg1[i]);
+#pragma unroll
+      for (int j = 0; j < T; ++j) atomicAdd(dw0 + i * T + j, dg1[i] * h0[j]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ pool + duplicate
+// y[b, co] = maxpool2x2(x[b, co/2]) : view(b*t, c/t).repeat_interleave(2, dim=1) == channel co <- co/2
+__global__ void pooldup_fwd_kernel(const float* __restrict__ x, float* y, int BC, int H, int W) {
+  const int H2 = H >> 1, W2 = W >> 1;
+  const size_t n = (size_t)BC * H2 * W2;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int w2 = idx % W2, h2 = (idx / W2) % H2;
+    const size_t bc = idx / ((size_t)W2 * H2);
+    const float* px = x + (bc * H + 2 * h2) * W + 2 * w2;
+    const float2 r0 = *reinterpret_cast<const float2*>(px);
+    const float2 r1 = *reinterpret_cast<const float2*>(px + W);
+    const float m = fmaxf(fmaxf(r0.x, r0.y), fmaxf(r1.x, r1.y));
+    const size_t yo = ((bc * 2) * H2 + h2) * W2 + w2;
+    y[yo] = m;
+    y[yo + (size_t)H2 * W2] = m;
+  }
+}
+// gradient goes to the FIRST maximum in window scan order (max_pool2d backward)
+__global__ void pooldup_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* dx, int BC, int H, int W) {
+  const int H2 = H >> 1, W2 = W >> 1;
+  const size_t n = (size_t)BC * H2 * W2;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int w2 = idx % W2, h2 = (idx / W2) % H2;
+    const size_t bc = idx / ((size_t)W2 * H2);
+    const size_t xo = (bc * H + 2 * h2) * W + 2 * w2;
+    const float2 r0 = *reinterpret_cast<const float2*>(x + xo);
+    const float2 r1 = *reinterpret_cast<const float2*>(x + xo + W);
+    int am = 0; float mv = r0.x;
+    if (r0.y > mv) { mv = r0.y; am = 1; }
+    if (r1.x > mv) { mv = r1.x; am = 2; }
+    if (r1.y > mv) { mv = r1.y; am = 3; }
+    const size_t yo = ((bc * 2) * H2 + h2) * W2 + w2;
+    const float g = dy[yo] + dy[yo + (size_t)H2 * W2];
+    *reinterpret_cast<float2*>(dx + xo) = make_float2(am == 0 ? g : 0.f, am == 1 ? g : 0.f);
+    *reinterpret_cast<float2*>(dx + xo + W) = make_float2(am == 2 ? g : 0.f, am == 3 ? g : 0.f);
+  }
+}
+
+// ------------------------------------------------------------------ UPPos front half
+__device__ __forceinline__ void ac_src(int o, float scale, int S, int& i0, int& i1, float& l1) {
+  const float src = scale * (float)o;           // align_corners=True: src = dst * (in-1)/(out-1)
+  i0 = (int)src;
+  i1 = i0 + (i0 < S - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+// x (BC, Sh, Sw) -> u (BC, 2Sh, 2Sw); pos (2Sh, 2Sw)
+__global__ void upmod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos, float* u, int BC, int Sh, int Sw) {
+  const int Oh = 2 * Sh, Ow = 2 * Sw;
+  const float sch = (float)(Sh - 1) / (float)(Oh - 1), scw = (float)(Sw - 1) / (float)(Ow - 1);
+  const size_t n = (size_t)BC * Oh * Ow;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int ox = idx % Ow, oy = (idx / Ow) % Oh;
+    const size_t bc = idx / ((size_t)Ow * Oh);
+    int y0, y1, x0, x1; float ly, lx;
+    ac_src(oy, sch, Sh, y0, y1, ly);
+    ac_src(ox, scw, Sw, x0, x1, lx);
+    const float* px = x + bc * Sh * Sw;
+    const float v = (1.f - ly) * ((1.f - lx) * px[y0 * Sw + x0] + lx * px[y0 * Sw + x1]) +
+                    ly * ((1.f - lx) * px[y1 * Sw + x0] + lx * px[y1 * Sw + x1]);
+    const float pm = 2.f / (1.f + expf(-pos[oy * Ow + ox])) - 1.f;
+    u[idx] = v + v * pm;
+  }
+}
+// dpos[y,x] += sum_{bc in chunk} du * v * 2 s (1-s);   grid.y = bc chunks
+__global__ void upmod_bwd_pos_kernel(const float* __restrict__ x, const float* __restrict__ pos, const float* __restrict__ du,
+                                     float* dpos, int BC, int Sh, int Sw, int chunk) {
+  const int Oh = 2 * Sh, Ow = 2 * Sw;
+  const float sch = (float)(Sh - 1) / (float)(Oh - 1), scw = (float)(Sw - 1) / (float)(Ow - 1);
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= Oh * Ow) return;
+  const int ox = pix % Ow, oy = pix / Ow;
+  int y0, y1, x0, x1; float ly, lx;
+  ac_src(oy, sch, Sh, y0, y1, ly);
+  ac_src(ox, scw, Sw, x0, x1, lx);
+  const int bc0 = blockIdx.y * chunk, bc1 = min(BC, bc0 + chunk);
+  float acc = 0.f;
+  for (int bc = bc0; bc < bc1; ++bc) {
+    const float* px = x + (size_t)bc * Sh * Sw;
+    const float v = (1.f - ly) * ((1.f - lx) * px[y0 * Sw + x0] + lx * px[y0 * Sw + x1]) +
+                    ly * ((1.f - lx) * px[y1 * Sw + x0] + lx * px[y1 * Sw + x1]);
+    acc += du[(size_t)bc * Oh * Ow + pix] * v;
+  }
+  const float sg = 1.f / (1.f + expf(-pos[pix]));
+  atomicAdd(dpos + pix, acc * 2.f * sg * (1.f - sg));
+}
+// dx[bc, yi, xi] = sum over the output pixels that sample (yi, xi) of weight * du * (1 + posm)
+__global__ void upmod_bwd_x_kernel(const float* __restrict__ pos, const float* __restrict__ du, float* dx, int BC, int Sh, int Sw) {
+  const int Oh = 2 * Sh, Ow = 2 * Sw;
+  const float sch = (float)(Sh - 1) / (float)(Oh - 1), scw = (float)(Sw - 1) / (float)(Ow - 1);
+  const size_t n = (size_t)BC * Sh * Sw;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int xi = idx % Sw, yi = (idx / Sw) % Sh;
+    const size_t bc = idx / ((size_t)Sw * Sh);
+    const int ylo = max(0, 2 * yi - 2), yhi = min(Oh - 1, 2 * yi + 3);
+    const int xlo = max(0, 2 * xi - 2), xhi = min(Ow - 1, 2 * xi + 3);
+    const float* g = du + bc * Oh * Ow;
+    float acc = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      int y0, y1; float ly;
+      ac_src(oy, sch, Sh, y0, y1, ly);
+      const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        int x0, x1; float lx;
+        ac_src(ox, scw, Sw, x0, x1, lx);
+        const float wx = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
+        if (wx == 0.f) continue;
+        const float pm = 2.f / (1.f + expf(-pos[oy * Ow + ox])) - 1.f;
+        acc += wy * wx * g[oy * Ow + ox] * (1.f + pm);
+      }
+    }
+    dx[idx] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ discriminator tail
+__device__ __forceinline__ void hp_src(int o, float scale, int S, int& i0, int& i1, float& l1) {
+  float src = ((float)o + 0.5f) * scale - 0.5f;     // align_corners=False
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  i1 = i0 + (i0 < S - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+__global__ void dtail_fwd_kernel(const float* __restrict__ o2, const float* __restrict__ o3, const float* __restrict__ alpha,
+                                 float* fused, int B, int H2, int W2, int T3, int H3, int W3) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * H2 * W2) return;
+  const int x = idx % W2, y = (idx / W2) % H2, b = idx / (W2 * H2);
+  const float sh = (float)H3 / (float)H2, sw = (float)W3 / (float)W2;
+  int y0, y1, x0, x1; float ly, lx;
+  hp_src(y, sh, H3, y0, y1, ly);
+  hp_src(x, sw, W3, x0, x1, lx);
+  float m00 = 0.f, m01 = 0.f, m10 = 0.f, m11 = 0.f;
+  for (int t = 0; t < T3; ++t) {
+    const float* p = o3 + ((size_t)b * T3 + t) * H3 * W3;
+    m00 += p[y0 * W3 + x0]; m01 += p[y0 * W3 + x1]; m10 += p[y1 * W3 + x0]; m11 += p[y1 * W3 + x1];
+  }
+  const float it = 1.f / (float)T3;
+  m00 *= it; m01 *= it; m10 *= it; m11 *= it;
+  float up;
+  if (H3 == H2 && W3 == W2) up = m00;
+  else up = (1.f - ly) * ((1.f - lx) * m00 + lx * m01) + ly * ((1.f - lx) * m10 + lx * m11);
+  const float sg = 1.f / (1.f + expf(-*alpha));
+  fused[idx] = sg * o2[idx] + up;
+}
+__global__ void dtail_bwd2_kernel(const float* __restrict__ o2, const float* __restrict__ alpha, const float* __restrict__ df,
+                                  float* do2, float* dalpha, int n) {
+  __shared__ float red[16];
+  const float sg = 1.f / (1.f + expf(-*alpha));
+  float acc = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float g = df[i];
+    if (do2) do2[i] = sg * g;
+    acc += g * o2[i];
+  }
+  acc = block_sum(acc, red);
+  if (dalpha && threadIdx.x == 0) atomicAdd(dalpha, acc * sg * (1.f - sg));
+}
+__global__ void dtail_bwd3_kernel(const float* __restrict__ df, float* do3, int B, int H2, int W2, int T3, int H3, int W3) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * H3 * W3) return;
+  const int xi = idx % W3, yi = (idx / W3) % H3, b = idx / (W3 * H3);
+  const float sh = (float)H3 / (float)H2, sw = (float)W3 / (float)W2;
+  const int ry = H2 / H3 > 0 ? H2 / H3 : 1, rx = W2 / W3 > 0 ? W2 / W3 : 1;
+  const int ylo = max(0, (yi - 1) * ry - 1), yhi = min(H2 - 1, (yi + 2) * ry);
+  const int xlo = max(0, (xi - 1) * rx - 1), xhi = min(W2 - 1, (xi + 2) * rx);
+  float acc = 0.f;
+  const bool same = (H3 == H2 && W3 == W2);
+  for (int y = ylo; y <= yhi; ++y) {
+    int y0, y1; float ly;
+    hp_src(y, sh, H3, y0, y1, ly);
+    const float wy = same ? (y == yi ? 1.f : 0.f) : ((y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f));
+    if (wy == 0.f) continue;
+    for (int x = xlo; x <= xhi; ++x) {
+      int x0, x1; float lx;
+      hp_src(x, sw, W3, x0, x1, lx);
+      const float wx = same ? (x == xi ? 1.f : 0.f) : ((x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f));
+      if (wx != 0.f) acc += wy * wx * df[((size_t)b * H2 + y) * W2 + x];
+    }
+  }
+  acc /= (float)T3;
+  for (int t = 0; t < T3; ++t) do3[(((size_t)b * T3 + t) * H3 + yi) * W3 + xi] = acc;
+}
+
+// ------------------------------------------------------------------ misc
+// db[c] += sum_{b, inner} dy * act'(y); one block per channel
+__global__ void bias_grad_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, float* db, int B, int C,
+                                 int64_t inner) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const size_t base = ((size_t)b * C + c) * inner;
+    for (int64_t i = threadIdx.x; i < inner; i += blockDim.x) {
+      float g = dy[base + i];
+      if (y) g = act_grad(g, y[base + i], act);
+      acc += g;
+    }
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) db[c] += acc;
+}
+__global__ void axpy_kernel(float* y, const float* __restrict__ x, float a, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+// torch.optim.Adam single-tensor math: m.lerp_(g, 1-b1); v = b2 v + (1-b2) g g;
+// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_kernel(float* p, const float* __restrict__ g, float* m, float* v, int64_t n, float step_size, float beta1,
+                            float beta2, float eps, float bc2_sqrt) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+static inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
+  int64_t g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace p2i
+using namespace p2i;
+
+extern "C" int p2i_attn_fwd(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, float* out,
+                            int B, int T, int HW, void* stream) {
+  P2I_REQUIRE(x && w0 && b0 && w1 && b1 && out, "null pointer");
+  P2I_REQUIRE(T == 16, "AttentionBlock is hard-wired to T=16 (layer.py:310)");
+  hipLaunchKernelGGL(attn_fwd_kernel<16>, dim3(ceil_div(HW, 256), B), dim3(256), 0, (hipStream_t)stream, x, w0, b0, w1, b1, out, B, HW);
+  return launch_status();
+}
+extern "C" int p2i_attn_bwd(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                            const float* dout, float* dw0, float* db0, float* dw1, float* db1, int B, int T, int HW, void* stream) {
+  P2I_REQUIRE(x && w0 && b0 && w1 && b1 && dout && dw0 && db0 && dw1 && db1, "null pointer");
+  P2I_REQUIRE(T == 16, "AttentionBlock is hard-wired to T=16 (layer.py:310)");
+  hipLaunchKernelGGL(attn_bwd_kernel<16>, dim3(ceil_div(HW, 256), B), dim3(256), 0, (hipStream_t)stream, x, w0, b0, w1, b1, dout,
+                     dw0, db0, dw1, db1, B, HW);
+  return launch_status();
+}
+extern "C" int p2i_pooldup_fwd(const float* x, float* y, int B, int C, int H, int W, void* stream) {
+  P2I_REQUIRE(x && y, "null pointer");
+  P2I_REQUIRE(H % 2 == 0 && W % 2 == 0, "pooldup needs even H, W");
+  const int64_t n = (int64_t)B * C * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(pooldup_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, B * C, H, W);
+  return launch_status();
+}
+extern "C" int p2i_pooldup_bwd(const float* x, const float* dy, float* dx, int B, int C, int H, int W, void* stream) {
+  P2I_REQUIRE(x && dy && dx, "null pointer");
+  P2I_REQUIRE(H % 2 == 0 && W % 2 == 0, "pooldup needs even H, W");
+  const int64_t n = (int64_t)B * C * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(pooldup_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, B * C, H, W);
+  return launch_status();
+}
+extern "C" int p2i_upmod_fwd(const float* x, const float* pos, float* u, int B, int C, int S, int S2w, void* stream) {
+  P2I_REQUIRE(x && pos && u, "null pointer");
+  const int64_t n = (int64_t)B * C * 4 * S * S2w;
+  hipLaunchKernelGGL(upmod_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, pos, u, B * C, S, S2w);
+  return launch_status();
+}
+extern "C" int p2i_upmod_bwd(const float* x, const float* pos, const float* du, float* dx, float* dpos, int B, int C, int S,
+                             int S2w, void* stream) {
+  P2I_REQUIRE(x && pos && du, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int BC = B * C;
+  if (dpos) {
+    const int chunk = 16;
+    hipLaunchKernelGGL(upmod_bwd_pos_kernel, dim3(ceil_div(4 * S * S2w, 256), ceil_div(BC, chunk)), dim3(256), 0, s, x, pos, du, dpos,
+                       BC, S, S2w, chunk);
+  }
+  if (dx) {
+    const int64_t n = (int64_t)BC * S * S2w;
+    hipLaunchKernelGGL(upmod_bwd_x_kernel, dim3(grid_for(n)), dim3(256), 0, s, pos, du, dx, BC, S, S2w);
+  }
+  return launch_status();
+}
+extern "C" int p2i_dtail_fwd(const float* out2d, const float* out3d, const float* alpha2d, float* fused, int B, int H2, int W2,
+                             int T3, int H3, int W3, void* stream) {
+  P2I_REQUIRE(out2d && out3d && alpha2d && fused, "null pointer");
+  hipLaunchKernelGGL(dtail_fwd_kernel, dim3(ceil_div(B * H2 * W2, 256)), dim3(256), 0, (hipStream_t)stream, out2d, out3d, alpha2d,
+                     fused, B, H2, W2, T3, H3, W3);
+  return launch_status();
+}
+extern "C" int p2i_dtail_bwd(const float* out2d, const float* alpha2d, const float* dfused, float* dout2d, float* dout3d,
+                             float* dalpha2d, int B, int H2, int W2, int T3, int H3, int W3, void* stream) {
+  P2I_REQUIRE(out2d && alpha2d && dfused, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = B * H2 * W2;
+  hipLaunchKernelGGL(dtail_bwd2_kernel, dim3(min(ceil_div(n, 256), 64)), dim3(256), 0, s, out2d, alpha2d, dfused, dout2d, dalpha2d, n);
+  if (dout3d)
+    hipLaunchKernelGGL(dtail_bwd3_kernel, dim3(ceil_div(B * H3 * W3, 256)), dim3(256), 0, s, dfused, dout3d, B, H2, W2, T3, H3, W3);
+  return launch_status();
+}
+extern "C" int p2i_bias_grad(const float* dy, const float* y_act, int act, float* db, int B, int C, int64_t inner, void* stream) {
+  P2I_REQUIRE(dy && db, "null pointer");
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, y_act, act, db, B, C, inner);
+  return launch_status();
+}
+extern "C" int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stream) {
+  P2I_REQUIRE(y && x, "null pointer");
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, x, a, n);
+  return launch_status();
+}
+extern "C" int p2i_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        int step, void* stream) {
+  P2I_REQUIRE(p && g && m && v && step >= 1, "bad adam arguments");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(lr / bc1), beta1,
+                     beta2, eps, (float)sqrt(bc2));
+  return launch_status();
+}

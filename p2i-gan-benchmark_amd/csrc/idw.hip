@@ -1,0 +1,226 @@
+// Gauge-point injection: nonzero(mask) compaction + brute-force 3-D 4-NN inverse-distance
+// weighting (InputBlock.forward layer.py:324-361, idw_3d_knn layer.py:259-293, grid layer.py:246-256).
+//
+// Bit-level contract with the reference's CPU path (verified in oracle/idw_knn.c against torch):
+//  * torch.cdist (r > 25) evaluates d^2 as the 5-term sgemm row  [-2x,-2y,-2z,|q|^2,1] . [px,py,pz,1,|p|^2]
+//    which MKL accumulates as one k-ordered fmaf chain; sqrt(clamp_min(0)) follows.  The kernel runs
+//    the identical chain (v_mul, v_fma, v_fma, v_add, v_add), so distances agree to the bit and the
+//    (t-1)/(t+1) near-ties that a shared gauge mask produces resolve the same way.
+//  * torch.topk (N >= 256 -> std::partial_sort) keeps a 4-entry max-heap and replaces the root
+//    only on STRICTLY smaller d; the kernel replays libstdc++'s heap moves in registers.
+#include "common.h"
+
+namespace p2i {
+
+struct HeapE { float d; int i; };
+
+// libstdc++ __adjust_heap(first, 0, 4, x) + __push_heap: x replaces the root of the max-heap
+__device__ __forceinline__ void heap4_replace_root(HeapE& h0, HeapE& h1, HeapE& h2, HeapE& h3, const HeapE x) {
+  if (h2.d < h1.d) {          // larger child is 1 (ties pick 2)
+    h0 = h1; h1 = h3;         // hole moves 0 -> 1 -> 3
+    if (h1.d < x.d) { h3 = h1; if (h0.d < x.d) { h1 = h0; h0 = x; } else h1 = x; }
+    else h3 = x;
+  } else {
+    h0 = h2;                  // hole moves 0 -> 2
+    if (h0.d < x.d) { h2 = h0; h0 = x; } else h2 = x;
+  }
+}
+// __make_heap on 4 elements
+__device__ __forceinline__ void heap4_make(HeapE& h0, HeapE& h1, HeapE& h2, HeapE& h3) {
+  if (!(h3.d < h1.d)) { const HeapE t = h1; h1 = h3; h3 = t; }   // parent = 1
+  const HeapE x = h0;                                            // parent = 0: __adjust_heap(first,0,4,x)
+  if (h2.d < h1.d) {
+    h0 = h1; h1 = h3;
+    if (h1.d < x.d) { h3 = h1; if (h0.d < x.d) { h1 = h0; h0 = x; } else h1 = x; }
+    else h3 = x;
+  } else {
+    h0 = h2;
+    if (h0.d < x.d) { h2 = h0; h0 = x; } else h2 = x;
+  }
+}
+// __sort_heap on 4 elements -> ascending h0..h3
+__device__ __forceinline__ void heap4_sort(HeapE& h0, HeapE& h1, HeapE& h2, HeapE& h3) {
+  {  // len 4 -> 3: value = h3, h3 = root, adjust(first,0,3,value)
+    const HeapE x = h3; h3 = h0;
+    if (h2.d < h1.d) { h0 = h1; if (h0.d < x.d) { h1 = h0; h0 = x; } else h1 = x; }
+    else { h0 = h2; if (h0.d < x.d) { h2 = h0; h0 = x; } else h2 = x; }
+  }
+  {  // len 3 -> 2: value = h2, h2 = root, adjust(first,0,2,value): hole -> 1
+    const HeapE x = h2; h2 = h0;
+    h0 = h1;
+    if (h0.d < x.d) { h1 = h0; h0 = x; } else h1 = x;
+  }
+  {  // len 2 -> 1
+    const HeapE x = h1; h1 = h0; h0 = x;
+  }
+}
+
+// ---- compaction of mask > 0 in (t, y, x) order
+__global__ void idw_count_kernel(const float* __restrict__ mask, int32_t* frame_count, int HW) {
+  __shared__ float red[16];
+  const float* m = mask + (size_t)blockIdx.x * HW;
+  float c = 0.f;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) c += (m[i] > 0.f) ? 1.f : 0.f;
+  c = block_sum(c, red);
+  if (threadIdx.x == 0) frame_count[blockIdx.x] = (int)c;
+}
+__global__ __launch_bounds__(256) void idw_compact_kernel(const float* __restrict__ mask, const int32_t* __restrict__ frame_count,
+                                                         const float* __restrict__ gx, const float* __restrict__ gy,
+                                                         const float* __restrict__ gz, int32_t* pt_pos, int32_t* pt_count,
+                                                         float* pt_xyzn, int T, int H, int W) {
+  __shared__ int wsum[4];
+  __shared__ int s_base;
+  const int bt = blockIdx.x, b = bt / T, t = bt % T, HW = H * W, Q = T * HW;
+  if (threadIdx.x == 0) {
+    int off = 0;
+    for (int k = 0; k < t; ++k) off += frame_count[b * T + k];
+    s_base = off;
+    if (t == T - 1) pt_count[b] = off + frame_count[bt];
+  }
+  __syncthreads();
+  int base = s_base;
+  const float* m = mask + (size_t)bt * HW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float Wd = (float)max(W - 1, 1), Hd = (float)max(H - 1, 1), Td = (float)max(T - 1, 1);
+  for (int i0 = 0; i0 < HW; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    const bool on = i < HW && m[i] > 0.f;
+    const unsigned long long bal = __ballot(on);
+    const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int k = 0; k < 4; ++k) { if (k < wave) woff += wsum[k]; tot += wsum[k]; }
+    if (on) {
+      const int j = base + woff + rank;
+      const int y = i / W, x = i - y * W;
+      pt_pos[(size_t)b * Q + j] = t * HW + i;
+      // points: tx/(W-1), ty/(H-1), tz/(D-1) (layer.py:335-342); |p|^2 = (x^2 + y^2) + z^2 unfused
+      const float px = __fdiv_rn((float)x, Wd), py = __fdiv_rn((float)y, Hd), pz = __fdiv_rn((float)t, Td);
+      const float pn = __fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz));
+      *reinterpret_cast<float4*>(pt_xyzn + ((size_t)b * Q + j) * 4) = make_float4(px, py, pz, pn);
+    }
+    base += tot;
+    __syncthreads();
+  }
+  (void)gx; (void)gy; (void)gz;
+}
+
+// ---- 4-NN + IDW.  thread = one query voxel; points streamed through scalar loads (uniform index)
+__global__ __launch_bounds__(256) void idw_knn_kernel(const float* __restrict__ vals, const float* __restrict__ gx,
+                                                     const float* __restrict__ gy, const float* __restrict__ gz,
+                                                     const int32_t* __restrict__ pt_pos, const int32_t* __restrict__ pt_count,
+                                                     const float4* __restrict__ pt_xyzn, float* out, int32_t* sel_idx,
+                                                     float* sel_w, int T, int H, int W, float tau) {
+  const int b = blockIdx.y, HW = H * W, Q = T * HW;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= Q) return;
+  const int N = pt_count[b];
+  const size_t qo = (size_t)b * Q + q;
+  if (N < 4) {       // N == 0: zeros (layer.py:330-332); 0 < N < 4: reference raises in topk
+    out[qo] = 0.f;
+    if (sel_idx) {
+      *reinterpret_cast<int4*>(sel_idx + qo * 4) = make_int4(0, 0, 0, 0);
+      *reinterpret_cast<float4*>(sel_w + qo * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+  const int t = q / HW, rem = q - t * HW, y = rem / W, x = rem - y * W;
+  const float qx = gx[x], qy = gy[y], qz = gz[t];
+  const float a0 = -2.f * qx, a1 = -2.f * qy, a2 = -2.f * qz;
+  const float n1 = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
+  const float4* pts = pt_xyzn + (size_t)b * Q;
+
+  auto dist2 = [&](const float4 p) {
+    float acc = __fmul_rn(a0, p.x);
+    acc = __fmaf_rn(a1, p.y, acc);
+    acc = __fmaf_rn(a2, p.z, acc);
+    acc = __fadd_rn(acc, n1);       // fma(n1, 1, acc)
+    acc = __fadd_rn(acc, p.w);      // fma(1, |p|^2, acc)
+    return acc;
+  };
+  HeapE h0, h1, h2, h3;
+  float r2;                         // d^2 of the current root (fast reject)
+  {
+    const float d0 = dist2(pts[0]), d1 = dist2(pts[1]), d2 = dist2(pts[2]), d3 = dist2(pts[3]);
+    h0 = {sqrtf(fmaxf(d0, 0.f)), 0}; h1 = {sqrtf(fmaxf(d1, 0.f)), 1};
+    h2 = {sqrtf(fmaxf(d2, 0.f)), 2}; h3 = {sqrtf(fmaxf(d3, 0.f)), 3};
+    heap4_make(h0, h1, h2, h3);
+    r2 = h0.d * h0.d * 1.000001f + 1e-30f;
+  }
+  // fast reject: r2 = fl(fl(r*r)*(1+2^-20)) > r^2 exactly, so c2 >= r2 implies sqrt_rn(c2) >= r (no insert,
+  // as std::partial_sort's strict comparison demands); below r2 the exact d-space test decides.
+  for (int j = 4; j < N; ++j) {
+    const float c2 = dist2(pts[j]);
+    if (c2 < r2) {
+      const float dc = sqrtf(fmaxf(c2, 0.f));
+      if (dc < h0.d) {
+        heap4_replace_root(h0, h1, h2, h3, HeapE{dc, j});
+        r2 = h0.d * h0.d * 1.000001f + 1e-30f;
+      }
+    }
+  }
+  heap4_sort(h0, h1, h2, h3);
+  // weights (layer.py:283-290): inv = 1/(d+tau); w = inv*inv; w /= (sum + 1e-12); out = sum(v*w)
+  const float i0 = __fdiv_rn(1.f, h0.d + tau), i1 = __fdiv_rn(1.f, h1.d + tau);
+  const float i2 = __fdiv_rn(1.f, h2.d + tau), i3 = __fdiv_rn(1.f, h3.d + tau);
+  float w0 = i0 * i0, w1 = i1 * i1, w2 = i2 * i2, w3 = i3 * i3;
+  const float ws = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(w0, w1), w2), w3), 1e-12f);
+  w0 = __fdiv_rn(w0, ws); w1 = __fdiv_rn(w1, ws); w2 = __fdiv_rn(w2, ws); w3 = __fdiv_rn(w3, ws);
+  const int32_t* pp = pt_pos + (size_t)b * Q;
+  const float* vb = vals + (size_t)b * Q;
+  const float v0 = vb[pp[h0.i]], v1 = vb[pp[h1.i]], v2 = vb[pp[h2.i]], v3 = vb[pp[h3.i]];
+  out[qo] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(v0, w0), __fmul_rn(v1, w1)), __fmul_rn(v2, w2)), __fmul_rn(v3, w3));
+  if (sel_idx) {
+    *reinterpret_cast<int4*>(sel_idx + qo * 4) = make_int4(pp[h0.i], pp[h1.i], pp[h2.i], pp[h3.i]);
+    *reinterpret_cast<float4*>(sel_w + qo * 4) = make_float4(w0, w1, w2, w3);
+  }
+}
+
+// backward: d vals[pos] += w * dout[q]   (values enter the output linearly; weights are data)
+__global__ void idw_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ sel_idx, const float* __restrict__ sel_w,
+                               float* dvals, int Q, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float g = dout[i];
+    if (g == 0.f) continue;
+    const size_t b = i / Q;
+    const int4 id = *reinterpret_cast<const int4*>(sel_idx + i * 4);
+    const float4 w = *reinterpret_cast<const float4*>(sel_w + i * 4);
+    float* dv = dvals + b * Q;
+    if (w.x != 0.f) atomicAdd(dv + id.x, g * w.x);
+    if (w.y != 0.f) atomicAdd(dv + id.y, g * w.y);
+    if (w.z != 0.f) atomicAdd(dv + id.z, g * w.z);
+    if (w.w != 0.f) atomicAdd(dv + id.w, g * w.w);
+  }
+}
+
+}  // namespace p2i
+using namespace p2i;
+
+extern "C" int p2i_idw_fwd(const float* vals_src, const float* mask, const float* grid_x, const float* grid_y,
+                           const float* grid_z, float* out, int32_t* pt_pos, int32_t* pt_count, int32_t* frame_count,
+                           float* pt_xyzn, int32_t* sel_idx, float* sel_w, int B, int T, int H, int W, float tau, void* stream) {
+  P2I_REQUIRE(vals_src && mask && grid_x && grid_y && grid_z && out && pt_pos && pt_count && frame_count && pt_xyzn,
+              "null pointer");
+  P2I_REQUIRE((sel_idx == nullptr) == (sel_w == nullptr), "sel_idx and sel_w go together");
+  P2I_REQUIRE((long long)B * T * H * W < (1ll << 29), "IDW problem too large");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(idw_count_kernel, dim3(B * T), dim3(256), 0, s, mask, frame_count, H * W);
+  hipLaunchKernelGGL(idw_compact_kernel, dim3(B * T), dim3(256), 0, s, mask, frame_count, grid_x, grid_y, grid_z, pt_pos, pt_count,
+                     pt_xyzn, T, H, W);
+  hipLaunchKernelGGL(idw_knn_kernel, dim3(ceil_div(T * H * W, 256), B), dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos,
+                     pt_count, reinterpret_cast<const float4*>(pt_xyzn), out, sel_idx, sel_w, T, H, W, tau);
+  return launch_status();
+}
+
+extern "C" int p2i_idw_bwd(const float* dout, const int32_t* pt_pos, const int32_t* sel_idx, const float* sel_w, float* dvals_src,
+                           int B, int T, int H, int W, void* stream) {
+  P2I_REQUIRE(dout && sel_idx && sel_w && dvals_src, "null pointer");
+  (void)pt_pos;
+  const int Q = T * H * W;
+  const size_t total = (size_t)B * Q;
+  (void)hipMemsetAsync(dvals_src, 0, sizeof(float) * total, (hipStream_t)stream);
+  hipLaunchKernelGGL(idw_bwd_kernel, dim3(min((size_t)8192, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, sel_idx,
+                     sel_w, dvals_src, Q, total);
+  return launch_status();
+}

@@ -1,0 +1,242 @@
+// Weight preparation for the conv engine: DO-Conv fold (deconv_pytorch.py:111-127) and its
+// backward, plain <-> packed weight layouts, spectral-norm power iteration
+// (torch.nn.utils.spectral_norm; call sites layer.py:402-407, p2igan.py:141).
+#include <stdarg.h>
+#include "common.h"
+
+namespace p2i {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+__device__ __forceinline__ int pad32(int v) { return (v + 31) & ~31; }
+
+// ---- DO-Conv fold.  One thread per flat pair q = o'*I + i of the (O/g, I, 9) view.
+__global__ void fold_fwd_kernel(const float* __restrict__ W, const float* __restrict__ D, const float* __restrict__ Dd,
+                                int O, int I, int groups, int ksz, int identity_rep, float* wp_f, float* wp_d) {
+  const int Ig = I / groups, Og = O / groups;
+  const int Opad = pad32(O), Ipad = pad32(I);
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ksz == 1) {                       // DoW = W.reshape(O, I/g, 1, 1)
+    if (q >= O * Ig) return;
+    const int o = q / Ig, ci = q - o * Ig;
+    const int cin = (o / Og) * Ig + ci;
+    const float v = W[q];
+    wp_f[(size_t)cin * Opad + o] = v;
+    if (wp_d) wp_d[(size_t)o * Ipad + cin] = v;
+    return;
+  }
+  if (q >= Og * I) return;
+  const int i = q % I;                  // index into D (I, 9, 9)
+  const int o = q / Ig, ci = q - o * Ig;   // memory reinterpretation (O/g, I, 9) -> (O, I/g, 3, 3)
+  const int cin = (o / Og) * Ig + ci;
+  float w[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) w[s] = W[(size_t)q * 9 + s];
+#pragma unroll
+  for (int m = 0; m < 9; ++m) {
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < 9; ++s) acc += (D[(i * 9 + m) * 9 + s] + Dd[(i * 9 + m) * 9 + s]) * w[s];
+    if (identity_rep > 0 && m == 4 && cin == o / identity_rep) acc += 1.f;   // + x.repeat_interleave(rep,1), p2igan.py:79
+    wp_f[((size_t)m * I + cin) * Opad + o] = acc;
+    if (wp_d) wp_d[((size_t)m * O + o) * Ipad + cin] = acc;
+  }
+}
+
+// dW (O/g, I, 9) from packed dDoW: dW[q][s] = sum_m dDoW[q][m] * (D+Dd)[i][m][s]
+__global__ void fold_bwd_w_kernel(const float* __restrict__ dwp, const float* __restrict__ D, const float* __restrict__ Dd,
+                                  int O, int I, int groups, int ksz, float* dW) {
+  const int Ig = I / groups, Og = O / groups, Opad = pad32(O);
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ksz == 1) {
+    if (q >= O * Ig) return;
+    const int o = q / Ig, ci = q - o * Ig;
+    dW[q] = dwp[(size_t)((o / Og) * Ig + ci) * Opad + o];
+    return;
+  }
+  if (q >= Og * I) return;
+  const int i = q % I, o = q / Ig, ci = q - o * Ig, cin = (o / Og) * Ig + ci;
+  float g[9];
+#pragma unroll
+  for (int m = 0; m < 9; ++m) g[m] = dwp[((size_t)m * I + cin) * Opad + o];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) {
+    float acc = 0.f;
+#pragma unroll
+    for (int m = 0; m < 9; ++m) acc += g[m] * (D[(i * 9 + m) * 9 + s] + Dd[(i * 9 + m) * 9 + s]);
+    dW[(size_t)q * 9 + s] = acc;
+  }
+}
+
+// dD[i][m][s] = sum_{o'} dDoW[o',i,m] * W[o',i,s]; block per i, thread per (m,s)
+__global__ void fold_bwd_d_kernel(const float* __restrict__ dwp, const float* __restrict__ W, int O, int I, int groups,
+                                  float* dD) {
+  const int i = blockIdx.x, ms = threadIdx.x;
+  if (ms >= 81) return;
+  const int m = ms / 9, s = ms - m * 9;
+  const int Ig = I / groups, Og = O / groups, Opad = pad32(O);
+  float acc = 0.f;
+  for (int op = 0; op < Og; ++op) {
+    const int q = op * I + i, o = q / Ig, ci = q - o * Ig, cin = (o / Og) * Ig + ci;
+    acc += dwp[((size_t)m * I + cin) * Opad + o] * W[(size_t)q * 9 + s];
+  }
+  dD[(i * 9 + m) * 9 + s] = acc;
+}
+
+// ---- plain (O, I, NT) <-> packed
+__global__ void pack_kernel(const float* __restrict__ w, int O, int I, int NT, const float* div_ptr, float* wp_f, float* wp_d) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= O * I * NT) return;
+  const int tap = idx % NT, i = (idx / NT) % I, o = idx / (NT * I);
+  float v = w[idx];
+  if (div_ptr) v = v / *div_ptr;
+  if (wp_f) wp_f[((size_t)tap * I + i) * pad32(O) + o] = v;
+  if (wp_d) wp_d[((size_t)tap * O + o) * pad32(I) + i] = v;
+}
+
+__global__ void unpack_dot_kernel(const float* __restrict__ dwp, const float* __restrict__ w, int O, int I, int NT, float* dot) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  const int n = O * I * NT;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    const int tap = idx % NT, i = (idx / NT) % I, o = idx / (NT * I);
+    acc += dwp[((size_t)tap * I + i) * pad32(O) + o] * w[idx];
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(dot, acc);
+}
+
+__global__ void unpack_kernel(const float* __restrict__ dwp, int O, int I, int NT, const float* sigma_ptr, const float* dot,
+                              const float* __restrict__ u, const float* __restrict__ v, float* dw) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= O * I * NT) return;
+  const int tap = idx % NT, i = (idx / NT) % I, o = idx / (NT * I);
+  float g = dwp[((size_t)tap * I + i) * pad32(O) + o];
+  if (sigma_ptr) {
+    const float sg = *sigma_ptr;
+    g = g / sg - (*dot / (sg * sg)) * u[o] * v[i * NT + tap];
+  }
+  dw[idx] = g;
+}
+
+// ---- spectral norm
+__global__ void sn_wtu_kernel(const float* __restrict__ w, const float* __restrict__ u, int O, int K, float* t) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float acc = 0.f;
+  for (int o = 0; o < O; ++o) acc += w[(size_t)o * K + k] * u[o];
+  t[k] = acc;
+}
+__global__ void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ v, int O, int K, float* s) {
+  const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= O) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += w[(size_t)o * K + k] * v[k];
+  acc = wave_sum(acc);
+  if (lane == 0) s[o] = acc;
+}
+// out = in / max(||in||, eps); optionally sigma = sum(out * in) (= u^T W v with the NEW u)
+__global__ void sn_normalize_kernel(const float* __restrict__ in, int n, float* out, float* sigma) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += in[i] * in[i];
+  const float nrm = fmaxf(sqrtf(block_sum(acc, red)), 1e-12f);
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float o = in[i] / nrm;
+    out[i] = o;
+    dot += o * in[i];
+  }
+  if (sigma) {
+    dot = block_sum(dot, red);
+    if (threadIdx.x == 0) *sigma = dot;
+  }
+}
+__global__ void sn_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float* out) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += a[i] * b[i];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) *out = acc;
+}
+
+}  // namespace p2i
+using namespace p2i;
+
+extern "C" int p2i_abi_version(void) { return 1; }
+extern "C" const char* p2i_last_error(void) { return p2i::g_err; }
+
+extern "C" int p2i_doconv_fold_fwd(const float* W, const float* D, const float* D_diag, int O, int I, int groups, int ksz,
+                                   int identity_rep, float* wp_f, float* wp_d, void* stream) {
+  P2I_REQUIRE(W && wp_f, "null pointer");
+  P2I_REQUIRE(ksz == 1 || ksz == 3, "DO-Conv kernel size must be 1 or 3");
+  P2I_REQUIRE(groups >= 1 && O % groups == 0 && I % groups == 0, "channels not divisible by groups");
+  P2I_REQUIRE(ksz == 1 || (D && D_diag), "3x3 DO-Conv needs D and D_diag");
+  hipStream_t s = (hipStream_t)stream;
+  const int nt = ksz * ksz, Opad = (O + 31) / 32 * 32, Ipad = (I + 31) / 32 * 32;
+  if (groups > 1 || Opad != O) (void)hipMemsetAsync(wp_f, 0, sizeof(float) * (size_t)nt * I * Opad, s);
+  if (wp_d && (groups > 1 || Ipad != I)) (void)hipMemsetAsync(wp_d, 0, sizeof(float) * (size_t)nt * O * Ipad, s);
+  const int n = (ksz == 1) ? O * (I / groups) : (O / groups) * I;
+  hipLaunchKernelGGL(fold_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, W, D, D_diag, O, I, groups, ksz, identity_rep, wp_f, wp_d);
+  return launch_status();
+}
+
+extern "C" int p2i_doconv_fold_bwd(const float* dwp_f, const float* W, const float* D, const float* D_diag, int O, int I,
+                                   int groups, int ksz, float* dW, float* dD, void* stream) {
+  P2I_REQUIRE(dwp_f && W && dW, "null pointer");
+  P2I_REQUIRE(ksz == 1 || (D && D_diag && dD), "3x3 DO-Conv needs D, D_diag, dD");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (ksz == 1) ? O * (I / groups) : (O / groups) * I;
+  hipLaunchKernelGGL(fold_bwd_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dwp_f, D, D_diag, O, I, groups, ksz, dW);
+  if (ksz == 3) hipLaunchKernelGGL(fold_bwd_d_kernel, dim3(I), dim3(128), 0, s, dwp_f, W, O, I, groups, dD);
+  return launch_status();
+}
+
+extern "C" int p2i_weight_pack(const float* w, int O, int I, int ntaps, const float* inv_div_ptr, float* wp_f, float* wp_d,
+                               void* stream) {
+  P2I_REQUIRE(w && (wp_f || wp_d), "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int Opad = (O + 31) / 32 * 32, Ipad = (I + 31) / 32 * 32;
+  if (wp_f && Opad != O) (void)hipMemsetAsync(wp_f, 0, sizeof(float) * (size_t)ntaps * I * Opad, s);
+  if (wp_d && Ipad != I) (void)hipMemsetAsync(wp_d, 0, sizeof(float) * (size_t)ntaps * O * Ipad, s);
+  hipLaunchKernelGGL(pack_kernel, dim3(ceil_div(O * I * ntaps, 256)), dim3(256), 0, s, w, O, I, ntaps, inv_div_ptr, wp_f, wp_d);
+  return launch_status();
+}
+
+extern "C" int p2i_weight_unpack_grad(const float* dwp_f, int O, int I, int ntaps, const float* w_orig, const float* sigma_ptr,
+                                      const float* u, const float* v, float* scratch, float* dw, void* stream) {
+  P2I_REQUIRE(dwp_f && dw, "null pointer");
+  P2I_REQUIRE(!sigma_ptr || (w_orig && u && v && scratch), "spectral-norm unpack needs w_orig, u, v, scratch");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = O * I * ntaps;
+  if (sigma_ptr) {
+    (void)hipMemsetAsync(scratch, 0, sizeof(float), s);
+    hipLaunchKernelGGL(unpack_dot_kernel, dim3(min(ceil_div(n, 256), 256)), dim3(256), 0, s, dwp_f, w_orig, O, I, ntaps, scratch);
+  }
+  hipLaunchKernelGGL(unpack_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dwp_f, O, I, ntaps, sigma_ptr, scratch, u, v, dw);
+  return launch_status();
+}
+
+extern "C" int p2i_spectral_norm(const float* w, int O, int K, float* u, float* v, int training, float* sigma, float* scratch,
+                                 void* stream) {
+  P2I_REQUIRE(w && u && v && sigma && scratch, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  float* t = scratch;        // K
+  float* sv = scratch + K;   // O
+  if (training) {
+    hipLaunchKernelGGL(sn_wtu_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, s, w, u, O, K, t);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, t, K, v, (float*)nullptr);
+    hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(O, 4)), dim3(256), 0, s, w, v, O, K, sv);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, sv, O, u, sigma);
+  } else {
+    hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(O, 4)), dim3(256), 0, s, w, v, O, K, sv);
+    hipLaunchKernelGGL(sn_dot_kernel, dim3(1), dim3(1024), 0, s, u, sv, O, sigma);
+  }
+  return launch_status();
+}

@@ -1,0 +1,410 @@
+"""Raw (non-autograd) operators over the C ABI of libp2i_hip.so.
+
+Every function takes/returns contiguous fp32 CUDA tensors, validates shapes on the host BEFORE
+any launch (a faulting kernel can reset the node), enqueues on torch's current stream and
+raises RuntimeError on failure.  No CPU path exists here by design.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _hip
+from ._hip import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH, ConvDesc  # noqa: F401
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.is_contiguous()):
+            raise RuntimeError("p2i ops need contiguous CUDA tensors (the HIP path has no CPU fallback)")
+        if t.dtype not in (torch.float32, torch.int32):
+            raise RuntimeError(f"unsupported dtype {t.dtype}")
+
+
+def pad32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+@dataclass(frozen=True)
+class ConvSpec:
+    """Static description of one convolution layer (2-D layers have kt = st = 1, pt = 0)."""
+    cin: int
+    cout: int
+    k: Tuple[int, int, int]
+    stride: Tuple[int, int, int] = (1, 1, 1)
+    pad: Tuple[int, int, int] = (0, 0, 0)
+
+    @property
+    def ntaps(self) -> int:
+        return self.k[0] * self.k[1] * self.k[2]
+
+    def out_dims(self, t, h, w):
+        return tuple((d + 2 * p - k) // s + 1 for d, p, k, s in zip((t, h, w), self.pad, self.k, self.stride))
+
+    def desc(self, b, t, h, w) -> ConvDesc:
+        to, ho, wo = self.out_dims(t, h, w)
+        return ConvDesc(b, self.cin, self.cout, t, h, w, to, ho, wo, *self.k, *self.stride, *self.pad)
+
+    def wp_f_shape(self):
+        return (self.ntaps, self.cin, pad32(self.cout))
+
+    def wp_d_shape(self):
+        return (self.ntaps, self.cout, pad32(self.cin))
+
+
+def _dims5(x: torch.Tensor):
+    if x.dim() == 4:
+        b, c, h, w = x.shape
+        return b, c, 1, h, w
+    b, c, t, h, w = x.shape
+    return b, c, t, h, w
+
+
+def conv_fwd(spec: ConvSpec, x, wp_f, bias=None, residual=None, act=ACT_NONE, out=None):
+    lib = _hip.load()
+    b, c, t, h, w = _dims5(x)
+    if c != spec.cin or tuple(wp_f.shape) != spec.wp_f_shape():
+        raise RuntimeError(f"conv_fwd: shape mismatch x={tuple(x.shape)} wp={tuple(wp_f.shape)} spec={spec}")
+    to, ho, wo = spec.out_dims(t, h, w)
+    oshape = (b, spec.cout, ho, wo) if x.dim() == 4 else (b, spec.cout, to, ho, wo)
+    y = out if out is not None else torch.empty(oshape, device=x.device, dtype=torch.float32)
+    if tuple(y.shape) != oshape or (residual is not None and tuple(residual.shape) != oshape):
+        raise RuntimeError("conv_fwd: output/residual shape mismatch")
+    if bias is not None and bias.numel() != spec.cout:
+        raise RuntimeError("conv_fwd: bias size mismatch")
+    _chk(x, wp_f, bias, residual, y)
+    d = spec.desc(b, t, h, w)
+    _hip.check(lib.p2i_conv_fwd(d, _ptr(x), _ptr(wp_f), _ptr(bias), _ptr(residual), _ptr(y), act, _stream()), "p2i_conv_fwd")
+    return y
+
+
+def conv_dgrad(spec: ConvSpec, dy, wp_d, in_shape, y_act=None, act=ACT_NONE):
+    """dx for input of shape in_shape; if y_act is given dy is first multiplied by act'(y_act)."""
+    lib = _hip.load()
+    if len(in_shape) == 4:
+        b, c, h, w = in_shape
+        t = 1
+    else:
+        b, c, t, h, w = in_shape
+    to, ho, wo = spec.out_dims(t, h, w)
+    eshape = (b, spec.cout, ho, wo) if len(in_shape) == 4 else (b, spec.cout, to, ho, wo)
+    if tuple(dy.shape) != eshape or c != spec.cin or tuple(wp_d.shape) != spec.wp_d_shape():
+        raise RuntimeError(f"conv_dgrad: shape mismatch dy={tuple(dy.shape)} expected {eshape}")
+    if y_act is not None and y_act.shape != dy.shape:
+        raise RuntimeError("conv_dgrad: y_act shape mismatch")
+    dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
+    _chk(dy, wp_d, y_act, dx)
+    d = spec.desc(b, t, h, w)
+    _hip.check(lib.p2i_conv_dgrad(d, _ptr(dy), _ptr(y_act), act, _ptr(wp_d), _ptr(dx), _stream()), "p2i_conv_dgrad")
+    return dx
+
+
+def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False):
+    """Packed weight gradient dwp_f [ntaps][cin][pad32(cout)] (+ bias gradient)."""
+    lib = _hip.load()
+    b, c, t, h, w = _dims5(x)
+    to, ho, wo = spec.out_dims(t, h, w)
+    eshape = (b, spec.cout, ho, wo) if x.dim() == 4 else (b, spec.cout, to, ho, wo)
+    if tuple(dy.shape) != eshape or c != spec.cin:
+        raise RuntimeError(f"conv_wgrad: shape mismatch dy={tuple(dy.shape)} expected {eshape}")
+    if y_act is not None and y_act.shape != dy.shape:
+        raise RuntimeError("conv_wgrad: y_act shape mismatch")
+    dwp = torch.zeros(spec.wp_f_shape(), device=x.device, dtype=torch.float32)
+    db = torch.zeros(spec.cout, device=x.device, dtype=torch.float32) if want_bias else None
+    _chk(x, dy, y_act, dwp, db)
+    d = spec.desc(b, t, h, w)
+    _hip.check(lib.p2i_conv_wgrad(d, _ptr(x), _ptr(dy), _ptr(y_act), act, _ptr(dwp), _ptr(db), _stream()), "p2i_conv_wgrad")
+    return dwp, db
+
+
+# --------------------------------------------------------------------------- weights
+def doconv_fold(W, D, D_diag, out_ch, in_ch, groups, ksz, identity_rep=0, need_d=True):
+    lib = _hip.load()
+    nt = ksz * ksz
+    exp_w = (out_ch, in_ch // groups, nt)
+    if tuple(W.shape) != exp_w:
+        raise RuntimeError(f"doconv_fold: W shape {tuple(W.shape)} != {exp_w}")
+    if ksz == 3 and (tuple(D.shape) != (in_ch, 9, 9) or tuple(D_diag.shape) != (in_ch, 9, 9)):
+        raise RuntimeError("doconv_fold: D/D_diag shape mismatch")
+    wp_f = torch.empty((nt, in_ch, pad32(out_ch)), device=W.device, dtype=torch.float32)
+    wp_d = torch.empty((nt, out_ch, pad32(in_ch)), device=W.device, dtype=torch.float32) if need_d else None
+    _chk(W, D, D_diag)
+    _hip.check(lib.p2i_doconv_fold_fwd(_ptr(W), _ptr(D), _ptr(D_diag), out_ch, in_ch, groups, ksz, identity_rep,
+                                       _ptr(wp_f), _ptr(wp_d), _stream()), "p2i_doconv_fold_fwd")
+    return wp_f, wp_d
+
+
+def doconv_fold_bwd(dwp_f, W, D, D_diag, out_ch, in_ch, groups, ksz):
+    lib = _hip.load()
+    if tuple(dwp_f.shape) != (ksz * ksz, in_ch, pad32(out_ch)):
+        raise RuntimeError("doconv_fold_bwd: dwp shape mismatch")
+    dW = torch.empty_like(W)
+    dD = torch.empty_like(D) if ksz == 3 else None
+    _chk(dwp_f, W, D, D_diag)
+    _hip.check(lib.p2i_doconv_fold_bwd(_ptr(dwp_f), _ptr(W), _ptr(D), _ptr(D_diag), out_ch, in_ch, groups, ksz,
+                                       _ptr(dW), _ptr(dD), _stream()), "p2i_doconv_fold_bwd")
+    return dW, dD
+
+
+def weight_pack(w, sigma=None, need_f=True, need_d=True):
+    """w (O, I, *k) -> packed wp_f / wp_d, optionally divided by the device scalar sigma."""
+    lib = _hip.load()
+    O, I = w.shape[0], w.shape[1]
+    nt = w[0, 0].numel()
+    wp_f = torch.empty((nt, I, pad32(O)), device=w.device, dtype=torch.float32) if need_f else None
+    wp_d = torch.empty((nt, O, pad32(I)), device=w.device, dtype=torch.float32) if need_d else None
+    _chk(w, sigma)
+    _hip.check(lib.p2i_weight_pack(_ptr(w), O, I, nt, _ptr(sigma), _ptr(wp_f), _ptr(wp_d), _stream()), "p2i_weight_pack")
+    return wp_f, wp_d
+
+
+def weight_unpack_grad(dwp_f, like, w_orig=None, sigma=None, u=None, v=None):
+    lib = _hip.load()
+    O, I = like.shape[0], like.shape[1]
+    nt = like[0, 0].numel()
+    if tuple(dwp_f.shape) != (nt, I, pad32(O)):
+        raise RuntimeError("weight_unpack_grad: dwp shape mismatch")
+    dw = torch.empty_like(like)
+    scratch = torch.empty(4, device=like.device, dtype=torch.float32) if sigma is not None else None
+    _chk(dwp_f, w_orig, sigma, u, v)
+    _hip.check(lib.p2i_weight_unpack_grad(_ptr(dwp_f), O, I, nt, _ptr(w_orig), _ptr(sigma), _ptr(u), _ptr(v),
+                                          _ptr(scratch), _ptr(dw), _stream()), "p2i_weight_unpack_grad")
+    return dw
+
+
+def spectral_norm(w, u, v, training: bool):
+    """In-place power iteration on u, v (training) and sigma (device scalar tensor of shape (1,))."""
+    lib = _hip.load()
+    O = w.shape[0]
+    K = w.numel() // O
+    if u.numel() != O or v.numel() != K:
+        raise RuntimeError("spectral_norm: u/v size mismatch")
+    sigma = torch.empty(1, device=w.device, dtype=torch.float32)
+    scratch = torch.empty(O + K + 4, device=w.device, dtype=torch.float32)
+    _chk(w, u, v)
+    _hip.check(lib.p2i_spectral_norm(_ptr(w), O, K, _ptr(u), _ptr(v), int(training), _ptr(sigma), _ptr(scratch), _stream()),
+               "p2i_spectral_norm")
+    return sigma
+
+
+# --------------------------------------------------------------------------- generator glue
+def attn_fwd(x, w0, b0, w1, b1):
+    lib = _hip.load()
+    B, T, H, W = x.shape
+    out = torch.empty_like(x)
+    _chk(x, w0, b0, w1, b1)
+    if w0.numel() != T * T or b0.numel() != T or w1.numel() != T * T or b1.numel() != T:
+        raise RuntimeError("attn_fwd: parameter size mismatch")
+    _hip.check(lib.p2i_attn_fwd(_ptr(x), _ptr(w0), _ptr(b0), _ptr(w1), _ptr(b1), _ptr(out), B, T, H * W, _stream()), "p2i_attn_fwd")
+    return out
+
+
+def attn_bwd(x, w0, b0, w1, b1, dout):
+    lib = _hip.load()
+    B, T, H, W = x.shape
+    if dout.shape != x.shape:
+        raise RuntimeError("attn_bwd: dout shape mismatch")
+    g = [torch.zeros_like(p) for p in (w0, b0, w1, b1)]
+    _chk(x, w0, b0, w1, b1, dout)
+    _hip.check(lib.p2i_attn_bwd(_ptr(x), _ptr(w0), _ptr(b0), _ptr(w1), _ptr(b1), _ptr(dout), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]),
+                                _ptr(g[3]), B, T, H * W, _stream()), "p2i_attn_bwd")
+    return g
+
+
+_LINSPACE = {}
+
+
+def _grid_tables(T, H, W, device):
+    """torch.linspace(0,1,n) tables of layer.py:246-256, computed on the host CPU exactly as the
+    reference's CPU path does (CPU and GPU linspace kernels differ in the last bit)."""
+    key = (T, H, W, str(device))
+    if key not in _LINSPACE:
+        _LINSPACE[key] = tuple(torch.linspace(0, 1, n).to(device) for n in (W, H, T))
+    return _LINSPACE[key]
+
+
+def idw_fwd(vals_src, mask, tau=0.05, save=True):
+    """vals_src, mask: (B,T,H,W).  Returns out and the saved selection (pt_pos, sel_idx, sel_w)."""
+    lib = _hip.load()
+    B, T, H, W = vals_src.shape
+    if mask.shape != vals_src.shape:
+        raise RuntimeError("idw_fwd: mask shape mismatch")
+    dev = vals_src.device
+    Q = T * H * W
+    gx, gy, gz = _grid_tables(T, H, W, dev)
+    out = torch.empty_like(vals_src)
+    pt_pos = torch.empty(B * Q, device=dev, dtype=torch.int32)
+    pt_count = torch.empty(B, device=dev, dtype=torch.int32)
+    frame_count = torch.empty(B * T, device=dev, dtype=torch.int32)
+    pt_xyzn = torch.empty(B * Q * 4, device=dev, dtype=torch.float32)
+    sel_idx = torch.empty(B * Q * 4, device=dev, dtype=torch.int32) if save else None
+    sel_w = torch.empty(B * Q * 4, device=dev, dtype=torch.float32) if save else None
+    _chk(vals_src, mask)
+    _hip.check(lib.p2i_idw_fwd(_ptr(vals_src), _ptr(mask), _ptr(gx), _ptr(gy), _ptr(gz), _ptr(out), _ptr(pt_pos), _ptr(pt_count),
+                               _ptr(frame_count), _ptr(pt_xyzn), _ptr(sel_idx), _ptr(sel_w), B, T, H, W, float(tau), _stream()),
+               "p2i_idw_fwd")
+    return out, (pt_pos, pt_count, sel_idx, sel_w)
+
+
+def idw_bwd(dout, saved):
+    lib = _hip.load()
+    B, T, H, W = dout.shape
+    pt_pos, _, sel_idx, sel_w = saved
+    dvals = torch.empty_like(dout)
+    _chk(dout)
+    _hip.check(lib.p2i_idw_bwd(_ptr(dout), _ptr(pt_pos), _ptr(sel_idx), _ptr(sel_w), _ptr(dvals), B, T, H, W, _stream()), "p2i_idw_bwd")
+    return dvals
+
+
+def pooldup_fwd(x):
+    lib = _hip.load()
+    B, Cc, H, W = x.shape
+    y = torch.empty((B, 2 * Cc, H // 2, W // 2), device=x.device, dtype=torch.float32)
+    _chk(x)
+    _hip.check(lib.p2i_pooldup_fwd(_ptr(x), _ptr(y), B, Cc, H, W, _stream()), "p2i_pooldup_fwd")
+    return y
+
+
+def pooldup_bwd(x, dy):
+    lib = _hip.load()
+    B, Cc, H, W = x.shape
+    if tuple(dy.shape) != (B, 2 * Cc, H // 2, W // 2):
+        raise RuntimeError("pooldup_bwd: dy shape mismatch")
+    dx = torch.empty_like(x)
+    _chk(x, dy)
+    _hip.check(lib.p2i_pooldup_bwd(_ptr(x), _ptr(dy), _ptr(dx), B, Cc, H, W, _stream()), "p2i_pooldup_bwd")
+    return dx
+
+
+def upmod_fwd(x, pos):
+    lib = _hip.load()
+    B, Cc, Sh, Sw = x.shape
+    if pos.numel() != 4 * Sh * Sw:
+        raise RuntimeError(f"upmod_fwd: pos has {pos.numel()} elements, expected {4 * Sh * Sw}")
+    u = torch.empty((B, Cc, 2 * Sh, 2 * Sw), device=x.device, dtype=torch.float32)
+    _chk(x, pos)
+    _hip.check(lib.p2i_upmod_fwd(_ptr(x), _ptr(pos), _ptr(u), B, Cc, Sh, Sw, _stream()), "p2i_upmod_fwd")
+    return u
+
+
+def upmod_bwd(x, pos, du, need_dx=True):
+    lib = _hip.load()
+    B, Cc, Sh, Sw = x.shape
+    if tuple(du.shape) != (B, Cc, 2 * Sh, 2 * Sw):
+        raise RuntimeError("upmod_bwd: du shape mismatch")
+    dx = torch.empty_like(x) if need_dx else None
+    dpos = torch.zeros_like(pos)
+    _chk(x, pos, du)
+    _hip.check(lib.p2i_upmod_bwd(_ptr(x), _ptr(pos), _ptr(du), _ptr(dx), _ptr(dpos), B, Cc, Sh, Sw, _stream()), "p2i_upmod_bwd")
+    return dx, dpos
+
+
+# --------------------------------------------------------------------------- discriminator tail
+def dtail_fwd(out2d, out3d, alpha2d):
+    lib = _hip.load()
+    B, c2, H2, W2 = out2d.shape
+    B3, c3, T3, H3, W3 = out3d.shape
+    if c2 != 1 or c3 != 1 or B3 != B:
+        raise RuntimeError("dtail_fwd: expects single-channel branch outputs")
+    fused = torch.empty((B, H2 * W2), device=out2d.device, dtype=torch.float32)
+    _chk(out2d, out3d, alpha2d)
+    _hip.check(lib.p2i_dtail_fwd(_ptr(out2d), _ptr(out3d), _ptr(alpha2d), _ptr(fused), B, H2, W2, T3, H3, W3, _stream()), "p2i_dtail_fwd")
+    return fused
+
+
+def dtail_bwd(out2d, out3d_shape, alpha2d, dfused, need_alpha=True):
+    lib = _hip.load()
+    B, _, H2, W2 = out2d.shape
+    _, _, T3, H3, W3 = out3d_shape
+    d2 = torch.empty_like(out2d)
+    d3 = torch.empty(out3d_shape, device=out2d.device, dtype=torch.float32)
+    da = torch.zeros_like(alpha2d) if need_alpha else None
+    _chk(out2d, alpha2d, dfused)
+    _hip.check(lib.p2i_dtail_bwd(_ptr(out2d), _ptr(alpha2d), _ptr(dfused), _ptr(d2), _ptr(d3), _ptr(da), B, H2, W2, T3, H3, W3,
+                                 _stream()), "p2i_dtail_bwd")
+    return d2, d3, da
+
+
+# --------------------------------------------------------------------------- losses / optimiser
+def recloss(pred, target, k1_alpha):
+    """Returns (out3 device tensor [pool, reg, pool+k1*reg], dpred)."""
+    lib = _hip.load()
+    B, T = pred.shape[0], pred.shape[1]
+    HW = pred[0, 0].numel()
+    if pred.shape != target.shape:
+        raise RuntimeError("recloss: shape mismatch")
+    out3 = torch.empty(3, device=pred.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred)
+    scratch = torch.empty(B * (T - 1) * HW + 4096, device=pred.device, dtype=torch.float32)
+    _chk(pred, target)
+    _hip.check(lib.p2i_recloss(_ptr(pred), _ptr(target), float(k1_alpha), _ptr(out3), _ptr(dpred), _ptr(scratch), B, T, HW, _stream()),
+               "p2i_recloss")
+    return out3, dpred
+
+
+_LOSS_TYPES = {"hinge": 0, "lsgan": 1}
+
+
+def gan_loss_d(logits_real, logits_fake, loss_type="hinge", real_label=1.0, fake_label=0.0):
+    lib = _hip.load()
+    if loss_type not in _LOSS_TYPES:
+        raise NotImplementedError(f"gan loss '{loss_type}' (reference nsgan applies BCELoss to raw logits and cannot run)")
+    n = logits_real.numel()
+    loss = torch.empty(1, device=logits_real.device, dtype=torch.float32)
+    da, db = torch.empty_like(logits_real), torch.empty_like(logits_fake)
+    _chk(logits_real, logits_fake)
+    _hip.check(lib.p2i_gan_loss(_ptr(logits_real), _ptr(logits_fake), n, _LOSS_TYPES[loss_type], 0, 1.0, real_label, fake_label,
+                                _ptr(loss), _ptr(da), _ptr(db), _stream()), "p2i_gan_loss")
+    return loss, da, db
+
+
+def gan_loss_g(logits, weight, loss_type="hinge", real_label=1.0):
+    lib = _hip.load()
+    if loss_type not in _LOSS_TYPES:
+        raise NotImplementedError(f"gan loss '{loss_type}'")
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    da = torch.empty_like(logits)
+    _chk(logits)
+    _hip.check(lib.p2i_gan_loss(_ptr(logits), None, logits.numel(), _LOSS_TYPES[loss_type], 1, float(weight), real_label, 0.0,
+                                _ptr(loss), _ptr(da), None, _stream()), "p2i_gan_loss")
+    return loss, da
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+    lib = _hip.load()
+    n = p.numel()
+    if not (g.numel() == n and m.numel() == n and v.numel() == n):
+        raise RuntimeError("adam_step: buffer size mismatch")
+    _chk(p, g, m, v)
+    _hip.check(lib.p2i_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, step, _stream()), "p2i_adam")
+
+
+def axpy_(y, x, a=1.0):
+    lib = _hip.load()
+    if y.numel() != x.numel():
+        raise RuntimeError("axpy_: size mismatch")
+    _chk(y, x)
+    _hip.check(lib.p2i_axpy(_ptr(y), _ptr(x), float(a), y.numel(), _stream()), "p2i_axpy")
+    return y
+
+
+def bias_grad(dy, y_act=None, act=ACT_NONE):
+    lib = _hip.load()
+    B, Cc = dy.shape[0], dy.shape[1]
+    inner = dy[0, 0].numel()
+    db = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
+    _chk(dy, y_act)
+    _hip.check(lib.p2i_bias_grad(_ptr(dy), _ptr(y_act), act, _ptr(db), B, Cc, inner, _stream()), "p2i_bias_grad")
+    return db

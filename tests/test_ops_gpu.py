@@ -1,0 +1,296 @@
+"""Per-kernel parity: HIP path (through the C ABI) vs the CPU oracle / torch fp32 on the same
+seeded inputs.  Tolerances are relative to max-abs of the expected tensor."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_OP = 2e-5       # single fp32 kernel: summation-order noise only
+TOL_WGRAD = 1e-4    # long atomically-combined reductions
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from p2igan_bench import ops as o
+    o._hip.load()
+    return o
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+CONV_CASES = [
+    # name, dims(2/3), B, Cin, Cout, in spatial, k, stride, pad, act, bias, residual
+    ("g3x3_64", 2, 2, 64, 64, (16, 16), (3, 3), (1, 1), (1, 1), "relu", False, True),
+    ("g3x3_128_s16", 2, 3, 128, 128, (16, 16), (3, 3), (1, 1), (1, 1), "none", False, True),
+    ("g3x3_tiny4", 2, 2, 512, 512, (4, 4), (3, 3), (1, 1), (1, 1), "none", False, False),
+    ("g3x3_w128", 2, 1, 64, 64, (24, 128), (3, 3), (1, 1), (1, 1), "relu", False, False),
+    ("proj1x1", 2, 2, 128, 64, (16, 16), (1, 1), (1, 1), (0, 0), "relu", True, True),
+    ("d2d_s2_odd", 2, 2, 16, 32, (20, 22), (3, 3), (2, 2), (1, 1), "leaky", True, False),
+    ("d2d_s2", 2, 2, 64, 128, (32, 32), (3, 3), (2, 2), (1, 1), "leaky", True, False),
+    ("d2d_to1", 2, 2, 256, 1, (8, 8), (3, 3), (1, 1), (1, 1), "none", True, False),
+    ("dense_in16", 2, 2, 16, 64, (16, 16), (3, 3), (1, 1), (1, 1), "none", False, False),
+    ("out_tanh", 2, 2, 64, 16, (16, 16), (1, 1), (1, 1), (0, 0), "tanh", False, False),
+    ("d3d_first", 3, 2, 1, 32, (8, 16, 16), (3, 3, 3), (1, 2, 2), (1, 1, 1), "leaky", True, False),
+    ("d3d_mid", 3, 2, 32, 64, (4, 16, 16), (3, 3, 3), (1, 2, 2), (1, 1, 1), "leaky", True, False),
+    ("d3d_tstride", 3, 2, 16, 16, (8, 8, 8), (3, 3, 3), (2, 1, 1), (1, 1, 1), "leaky", True, False),
+    ("d3d_1x1x1", 3, 2, 128, 1, (4, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0), "none", True, False),
+]
+
+
+def _act_cpu(y, act):
+    return {"none": lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.2), "tanh": torch.tanh}[act](y)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(ops, case):
+    name, nd, B, Cin, Cout, sp, k, st, pd, act, has_bias, has_res = case
+    act_code = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY, "tanh": ops.ACT_TANH}[act]
+    k3 = (1,) + k if nd == 2 else k
+    s3 = (1,) + st if nd == 2 else st
+    p3 = (0,) + pd if nd == 2 else pd
+    spec = ops.ConvSpec(Cin, Cout, k3, s3, p3)
+    x = _rand(B, Cin, *sp, seed=1).requires_grad_(True)
+    fan = Cin * int(np.prod(k))
+    w = _rand(Cout, Cin, *k, seed=2, scale=1.0 / np.sqrt(fan)).requires_grad_(True)
+    bias = _rand(Cout, seed=3, scale=0.1).requires_grad_(True) if has_bias else None
+    conv = F.conv2d if nd == 2 else F.conv3d
+    pre = conv(x, w, bias, st, pd)
+    res = _rand(*pre.shape, seed=4) if has_res else None
+    y = _act_cpu(pre, act)
+    out = y + res if has_res else y
+    gout = _rand(*out.shape, seed=5)
+    out.backward(gout)
+
+    dev = "cuda"
+    wp_f, wp_d = ops.weight_pack(w.detach().to(dev))
+    xg = x.detach().to(dev)
+    yg = ops.conv_fwd(spec, xg, wp_f, bias.detach().to(dev) if has_bias else None, res.to(dev) if has_res else None, act_code)
+    assert rel_err(yg.cpu().numpy(), out.detach().numpy()) < TOL_OP
+
+    # backward: dy_eff = gout * act'(y).  The HIP path gets the post-activation tensor (before residual).
+    y_act = y.detach().to(dev).contiguous() if act != "none" else None
+    dx = ops.conv_dgrad(spec, gout.to(dev), wp_d, tuple(x.shape), y_act, act_code)
+    assert rel_err(dx.cpu().numpy(), x.grad.numpy()) < TOL_OP
+    dwp, db = ops.conv_wgrad(spec, xg, gout.to(dev), y_act, act_code, want_bias=has_bias)
+    dw = ops.weight_unpack_grad(dwp, w.detach().to(dev))
+    assert rel_err(dw.cpu().numpy(), w.grad.numpy()) < TOL_WGRAD
+    if has_bias:
+        assert rel_err(db.cpu().numpy(), bias.grad.numpy()) < TOL_WGRAD
+
+
+@pytest.mark.parametrize("O,I,g,ksz,rep", [(64, 64, 1, 3, 0), (128, 128, 1, 3, 0), (64, 16, 4, 3, 4), (16, 64, 4, 1, 0)])
+def test_doconv_fold(ops, O, I, g, ksz, rep):
+    from oracle import p2i_oracle as orc
+    nt = ksz * ksz
+    W = _rand(O, I // g, nt, seed=1, scale=0.2).requires_grad_(True)
+    D = _rand(I, 9, 9, seed=2, scale=0.05).requires_grad_(True) if ksz == 3 else None
+    Dd = torch.eye(9).reshape(1, 9, 9).repeat(I, 1, 1) if ksz == 3 else None
+    dow = orc.doconv_fold(W, D, Dd, O, I, g, ksz)                       # (O, I/g, k, k)
+    x = _rand(2, I, 8, 8, seed=3)
+    y = F.conv2d(x, dow, None, 1, ksz // 2, 1, g)
+    if rep:
+        y = y + x.repeat_interleave(rep, dim=1)
+    gout = _rand(*y.shape, seed=4)
+    y.backward(gout)
+    dev = "cuda"
+    Wg, Dg, Ddg = W.detach().to(dev), (D.detach().to(dev) if D is not None else None), (Dd.to(dev) if Dd is not None else None)
+    wp_f, wp_d = ops.doconv_fold(Wg, Dg, Ddg, O, I, g, ksz, identity_rep=rep)
+    spec = ops.ConvSpec(I, O, (1, ksz, ksz), (1, 1, 1), (0, ksz // 2, ksz // 2))
+    yg = ops.conv_fwd(spec, x.to(dev), wp_f)
+    assert rel_err(yg.cpu().numpy(), y.detach().numpy()) < TOL_OP
+    dwp, _ = ops.conv_wgrad(spec, x.to(dev), gout.to(dev))
+    dW, dD = ops.doconv_fold_bwd(dwp, Wg, Dg, Ddg, O, I, g, ksz)
+    assert rel_err(dW.cpu().numpy(), W.grad.numpy()) < TOL_WGRAD
+    if ksz == 3:
+        assert rel_err(dD.cpu().numpy(), D.grad.numpy()) < TOL_WGRAD
+
+
+@pytest.mark.parametrize("shape", [(64, 16, 3, 3), (32, 1, 3, 3, 3), (1, 128, 1, 1, 1), (128, 128, 3, 3, 3)])
+def test_spectral_norm(ops, shape):
+    from oracle import p2i_oracle as orc
+    w = _rand(*shape, seed=1, scale=0.1)
+    O, K = shape[0], int(np.prod(shape[1:]))
+    u = F.normalize(_rand(O, seed=2), dim=0)
+    v = F.normalize(_rand(K, seed=3), dim=0)
+    p = {"l.weight_orig": w.clone().requires_grad_(True), "l.weight_u": u.clone(), "l.weight_v": v.clone()}
+    wn = orc.spectral_norm_weight(p, "l", True)
+    gw = _rand(*shape, seed=4)
+    wn.backward(gw)
+    dev = "cuda"
+    ug, vg, wg = u.to(dev), v.to(dev), w.to(dev)
+    sigma = ops.spectral_norm(wg, ug, vg, True)
+    assert rel_err(ug.cpu().numpy(), p["l.weight_u"].numpy()) < TOL_OP
+    assert rel_err(vg.cpu().numpy(), p["l.weight_v"].numpy()) < TOL_OP
+    wflat = w.reshape(O, shape[1], -1)
+    wp_f, _ = ops.weight_pack(wflat.to(dev), sigma)
+    nt = wflat.shape[2]
+    got = wp_f[:, :, :O].permute(2, 1, 0).reshape(shape).cpu()
+    assert rel_err(got.numpy(), wn.detach().numpy()) < TOL_OP
+    # gradient through weight / sigma
+    gflat = gw.reshape(O, shape[1], nt)
+    dwp = torch.zeros(nt, shape[1], ops.pad32(O))
+    dwp[:, :, :O] = gflat.permute(2, 1, 0)
+    dw = ops.weight_unpack_grad(dwp.to(dev), wflat.to(dev), wflat.to(dev), sigma, ug, vg)
+    assert rel_err(dw.cpu().numpy(), p["l.weight_orig"].grad.reshape(O, shape[1], nt).numpy()) < 1e-4
+    # eval mode: sigma from stored u, v, no update
+    u2, v2 = ug.clone(), vg.clone()
+    s2 = ops.spectral_norm(wg, u2, v2, False)
+    assert torch.equal(u2, ug) and torch.equal(v2, vg)
+    assert abs(float(s2) - float(sigma)) < 1e-4 * abs(float(sigma))
+
+
+def test_attention_block(ops):
+    from oracle import p2i_oracle as orc
+    B, T, H, W = 2, 16, 12, 20
+    x = _rand(B, T, H, W, seed=1).abs()
+    w0 = _rand(T, T, 1, seed=2, scale=0.3).requires_grad_(True)
+    b0 = _rand(T, seed=3, scale=0.1).requires_grad_(True)
+    w1 = _rand(T, T, 1, seed=4, scale=0.3).requires_grad_(True)
+    b1 = _rand(T, seed=5, scale=0.1).requires_grad_(True)
+    xs = x.permute(0, 2, 3, 1).contiguous().view(B * H * W, T, 1)
+    o = orc.attention_block(orc.attention_block(xs, w0, b0), w1, b1).view(B, H, W, T).permute(0, 3, 1, 2)
+    gout = _rand(B, T, H, W, seed=6) * (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(7)) < 0.2)
+    o.backward(gout)
+    dev = "cuda"
+    args = [t.detach().to(dev).contiguous() for t in (x, w0, b0, w1, b1)]
+    og = ops.attn_fwd(*args)
+    assert rel_err(og.cpu().numpy(), o.detach().numpy()) < TOL_OP
+    g = ops.attn_bwd(*args, gout.to(dev).contiguous())
+    for got, ref in zip(g, (w0, b0, w1, b1)):
+        assert rel_err(got.cpu().numpy(), ref.grad.numpy()) < TOL_WGRAD
+
+
+@pytest.mark.parametrize("kind", ["gauge", "few", "lattice", "block4"])
+def test_idw_matches_oracle_and_golden(ops, kind, golden):
+    from oracle import p2i_oracle as orc
+    from p2igan_bench.utils import seeded
+    T, H, W = 16, 32, 32
+    g = golden("idw.npz")
+    if kind == "block4":
+        mask = seeded.block_mask(H, W, 4, seed=9)
+        vals_pts = None
+    else:
+        mask = torch.from_numpy(g[kind + "_mask"])
+    mk = mask.reshape(1, 1, H, W).expand(2, T, H, W).contiguous()
+    src = _rand(2, T, H, W, seed=3).abs().requires_grad_(True)
+    outs = []
+    for b in range(2):
+        tz, ty, tx, pts = orc.mask_points(mk[b])
+        outs.append(orc.idw_3d_knn(pts, src[b][tz, ty, tx], (T, H, W)))
+    ref = torch.stack(outs)
+    gout = _rand(2, T, H, W, seed=4)
+    ref.backward(gout)
+    dev = "cuda"
+    og, saved = ops.idw_fwd(src.detach().to(dev), mk.to(dev))
+    e = (og.cpu() - ref.detach()).abs()
+    # selection must be IDENTICAL except where torch.topk's tie order is unspecified (N < 256 path)
+    frac_bad = float((e > 1e-5 * ref.detach().abs().max()).float().mean())
+    assert frac_bad <= (0.0 if kind in ("gauge", "block4", "lattice") else 2e-3), f"{kind}: {frac_bad}"
+    dv = ops.idw_bwd(gout.to(dev), saved)
+    if frac_bad == 0.0:
+        assert rel_err(dv.cpu().numpy(), src.grad.numpy()) < TOL_WGRAD
+
+
+def test_idw_empty_mask(ops):
+    src = _rand(1, 16, 8, 8, seed=1).cuda()
+    out, _ = ops.idw_fwd(src, torch.zeros_like(src))
+    assert float(out.abs().max()) == 0.0
+
+
+def test_pooldup(ops):
+    from oracle import p2i_oracle as orc
+    x = _rand(2, 64, 16, 24, seed=1).requires_grad_(True)
+    y = orc.pool_dup(x, 16)
+    gout = _rand(*y.shape, seed=2)
+    y.backward(gout)
+    yg = ops.pooldup_fwd(x.detach().cuda())
+    assert torch.equal(yg.cpu(), y.detach())
+    dx = ops.pooldup_bwd(x.detach().cuda(), gout.cuda())
+    assert rel_err(dx.cpu().numpy(), x.grad.numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("S", [2, 4, 16, 64])
+def test_upmod(ops, S):
+    x = _rand(2, 8, S, S, seed=1).requires_grad_(True)
+    pos = _rand(1, 1, 2 * S, 2 * S, seed=2, scale=0.5).requires_grad_(True)
+    u = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    u = u + u * (2 * torch.sigmoid(pos) - 1)
+    gout = _rand(*u.shape, seed=3)
+    u.backward(gout)
+    ug = ops.upmod_fwd(x.detach().cuda(), pos.detach().cuda())
+    assert rel_err(ug.cpu().numpy(), u.detach().numpy()) < TOL_OP
+    dx, dpos = ops.upmod_bwd(x.detach().cuda(), pos.detach().cuda(), gout.cuda())
+    assert rel_err(dx.cpu().numpy(), x.grad.numpy()) < TOL_OP
+    assert rel_err(dpos.cpu().numpy(), pos.grad.numpy()) < TOL_WGRAD
+
+
+@pytest.mark.parametrize("dims", [(8, 8, 2, 4, 4), (32, 32, 8, 16, 16), (8, 8, 4, 8, 8)])
+def test_dtail(ops, dims):
+    H2, W2, T3, H3, W3 = dims
+    o2 = _rand(2, 1, H2, W2, seed=1).requires_grad_(True)
+    o3 = _rand(2, 1, T3, H3, W3, seed=2).requires_grad_(True)
+    alpha = torch.tensor(0.3, requires_grad=True)
+    z2 = o3.mean(dim=2)
+    if z2.shape[-2:] != o2.shape[-2:]:
+        z2 = F.interpolate(z2, size=o2.shape[-2:], mode="bilinear", align_corners=False)
+    fused = (torch.sigmoid(alpha) * o2 + z2).view(2, -1)
+    gout = _rand(*fused.shape, seed=3)
+    fused.backward(gout)
+    fg = ops.dtail_fwd(o2.detach().cuda(), o3.detach().cuda(), alpha.detach().cuda().reshape(1))
+    assert rel_err(fg.cpu().numpy(), fused.detach().numpy()) < TOL_OP
+    d2, d3, da = ops.dtail_bwd(o2.detach().cuda(), tuple(o3.shape), alpha.detach().cuda().reshape(1), gout.cuda())
+    assert rel_err(d2.cpu().numpy(), o2.grad.numpy()) < TOL_OP
+    assert rel_err(d3.cpu().numpy(), o3.grad.numpy()) < TOL_OP
+    assert abs(float(da) - float(alpha.grad)) < 1e-4 * abs(float(alpha.grad)) + 1e-7
+
+
+def test_recloss_and_gan_losses(ops):
+    from oracle import p2i_oracle as orc
+    B, T, H, W = 2, 16, 16, 24
+    true = torch.rand(B, T, 1, H, W, generator=torch.Generator().manual_seed(1))
+    pred = (torch.tanh(_rand(B, T, 1, H, W, seed=2))).requires_grad_(True)
+    loss, pool, reg = orc.reconstruction_loss(pred, true, 0.05)
+    loss.backward()
+    out3, dpred = ops.recloss(pred.detach().cuda(), true.cuda(), 0.05)
+    o = out3.cpu().numpy()
+    assert abs(o[0] - float(pool)) < 1e-5 * abs(float(pool))
+    assert abs(o[1] - float(reg)) < 1e-4 * abs(float(reg))
+    assert abs(o[2] - float(loss)) < 1e-4 * abs(float(loss))
+    assert rel_err(dpred.cpu().numpy(), pred.grad.numpy()) < 1e-4
+    for lt in ("hinge", "lsgan"):
+        a = _rand(2, 64, seed=3).requires_grad_(True)
+        b = _rand(2, 64, seed=4).requires_grad_(True)
+        ld = (orc.gan_loss(a, True, lt, True) + orc.gan_loss(b, False, lt, True)) * 0.5
+        ld.backward()
+        l, da, db = ops.gan_loss_d(a.detach().cuda(), b.detach().cuda(), lt)
+        assert abs(float(l) - float(ld)) < 1e-5 * abs(float(ld))
+        assert rel_err(da.cpu().numpy(), a.grad.numpy()) < 1e-5 and rel_err(db.cpu().numpy(), b.grad.numpy()) < 1e-5
+        c = _rand(2, 64, seed=5).requires_grad_(True)
+        lg = orc.gan_loss(c, True, lt, False) * 0.01
+        lg.backward()
+        l2, dc = ops.gan_loss_g(c.detach().cuda(), 0.01, lt)
+        assert abs(float(l2) - float(lg)) < 1e-5 * abs(float(lg)) + 1e-9
+        assert rel_err(dc.cpu().numpy(), c.grad.numpy()) < 1e-5
+
+
+def test_adam_matches_torch(ops):
+    p = _rand(5000, seed=1)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-4, betas=(0.0, 0.99))
+    pg, m, v = p.cuda(), torch.zeros(5000).cuda(), torch.zeros(5000).cuda()
+    for step in range(1, 4):
+        g = _rand(5000, seed=10 + step)
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(pg, g.cuda(), m, v, 1e-4, 0.0, 0.99, 1e-8, step)
+    assert rel_err(pg.cpu().numpy(), ref.detach().numpy()) < 1e-6
+    assert float((pg.cpu() - p).abs().max()) > 1e-5
