@@ -66,10 +66,13 @@ def grid_points(D: int, H: int, W: int) -> torch.Tensor:
     return _GRID[key]
 
 
-def idw_3d_knn(points: torch.Tensor, values: torch.Tensor, shape: Tuple[int, int, int],
-               k: int = IDW_K, tau: float = IDW_TAU, chunk: int = IDW_CHUNK,
-               return_sel: bool = False):
-    """idw_3d_knn, layer.py:259-293 on the CPU fp32 path (rho == 2 branch)."""
+def idw_3d_knn_torch(points: torch.Tensor, values: torch.Tensor, shape: Tuple[int, int, int],
+                     k: int = IDW_K, tau: float = IDW_TAU, chunk: int = IDW_CHUNK, return_sel: bool = False):
+    """idw_3d_knn, layer.py:259-293 on the CPU fp32 path (rho == 2 branch), literally through
+    torch.cdist / torch.topk.  NOTE: cdist's sgemm rounding (hence which of two mathematically
+    equidistant gauges (t-1 / t+1) wins rank 4) depends on the MKL code path of the HOST CPU:
+    Intel AVX-512 hosts accumulate a k-ordered fmaf chain, the MI355X box's EPYC host does not.
+    Used for documentation and for timing the CPU baseline; parity uses ``idw_3d_knn`` below."""
     D, H, W = shape
     gp_all = grid_points(D, H, W)
     Q = gp_all.shape[0]
@@ -88,6 +91,60 @@ def idw_3d_knn(points: torch.Tensor, values: torch.Tensor, shape: Tuple[int, int
             idx_all[s:e] = i_k
     out = out.reshape(D, H, W)
     return (out, idx_all) if return_sel else out
+
+
+_CLIB = None
+
+
+def _c_lib():
+    """oracle/_build/libp2i_oracle.so (oracle/idw_knn.c), built on demand with gcc."""
+    global _CLIB
+    if _CLIB is None:
+        import ctypes
+        import os
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        so = os.path.join(here, "_build", "libp2i_oracle.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", here])
+        _CLIB = ctypes.CDLL(so)
+    return _CLIB
+
+
+def idw_select_c(points: torch.Tensor, shape: Tuple[int, int, int], tau: float = IDW_TAU):
+    """4-NN selection by oracle/idw_knn.c: the host-independent restatement of cdist's fmaf chain +
+    topk's partial_sort heap as captured from the reference on an Intel AVX-512 host (goldens).
+    Returns (sel int64 (Q,4), d float32 (Q,4)) sorted by ascending distance."""
+    import ctypes
+    D, H, W = shape
+    Q = D * H * W
+    gx, gy, gz = (torch.linspace(0, 1, n) for n in (W, H, D))
+    pts = points.detach().float().contiguous()
+    N = pts.shape[0]
+    if N < 4:
+        raise RuntimeError("selected index k out of range")      # torch.topk(k=4) on fewer than 4 points
+    out = torch.empty(Q, dtype=torch.float32)
+    sel = torch.empty(Q, 4, dtype=torch.int32)
+    seld = torch.empty(Q, 4, dtype=torch.float32)
+    dummy = torch.zeros(N, dtype=torch.float32)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    _c_lib().idw_knn4(P(gx), P(gy), P(gz), D, H, W, P(pts), P(dummy), N, ctypes.c_float(tau), P(out), P(sel), P(seld))
+    return sel.long(), seld
+
+
+def idw_3d_knn(points: torch.Tensor, values: torch.Tensor, shape: Tuple[int, int, int],
+               k: int = IDW_K, tau: float = IDW_TAU, chunk: int = IDW_CHUNK, return_sel: bool = False):
+    """idw_3d_knn, layer.py:259-293: selection by the pinned C restatement, weights/values in torch
+    (differentiable w.r.t. ``values`` exactly like the reference: weights are data)."""
+    assert k == 4
+    D, H, W = shape
+    sel, d_k = idw_select_c(points, shape, tau)
+    v_k = values[sel]
+    inv = 1.0 / (d_k + tau)
+    w = inv * inv
+    w = w / (w.sum(dim=1, keepdim=True) + 1e-12)
+    out = (v_k * w).sum(dim=1).reshape(D, H, W)
+    return (out, sel) if return_sel else out
 
 
 def mask_points(mask_b: torch.Tensor):

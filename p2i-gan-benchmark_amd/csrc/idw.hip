@@ -12,48 +12,24 @@
 
 namespace p2i {
 
-struct HeapE { float d; int i; };
+// Heap entries live in scalar registers (d = distance, i = point index); SWAP/MOVE keep both in step.
+#define HE_MOVE(a, b) do { a##d = b##d; a##i = b##i; } while (0)
+#define HE_SET(a, vd, vi) do { a##d = (vd); a##i = (vi); } while (0)
 
-// libstdc++ __adjust_heap(first, 0, 4, x) + __push_heap: x replaces the root of the max-heap
-__device__ __forceinline__ void heap4_replace_root(HeapE& h0, HeapE& h1, HeapE& h2, HeapE& h3, const HeapE x) {
-  if (h2.d < h1.d) {          // larger child is 1 (ties pick 2)
-    h0 = h1; h1 = h3;         // hole moves 0 -> 1 -> 3
-    if (h1.d < x.d) { h3 = h1; if (h0.d < x.d) { h1 = h0; h0 = x; } else h1 = x; }
-    else h3 = x;
-  } else {
-    h0 = h2;                  // hole moves 0 -> 2
-    if (h0.d < x.d) { h2 = h0; h0 = x; } else h2 = x;
-  }
-}
-// __make_heap on 4 elements
-__device__ __forceinline__ void heap4_make(HeapE& h0, HeapE& h1, HeapE& h2, HeapE& h3) {
-  if (!(h3.d < h1.d)) { const HeapE t = h1; h1 = h3; h3 = t; }   // parent = 1
-  const HeapE x = h0;                                            // parent = 0: __adjust_heap(first,0,4,x)
-  if (h2.d < h1.d) {
-    h0 = h1; h1 = h3;
-    if (h1.d < x.d) { h3 = h1; if (h0.d < x.d) { h1 = h0; h0 = x; } else h1 = x; }
-    else h3 = x;
-  } else {
-    h0 = h2;
-    if (h0.d < x.d) { h2 = h0; h0 = x; } else h2 = x;
-  }
-}
-// __sort_heap on 4 elements -> ascending h0..h3
-__device__ __forceinline__ void heap4_sort(HeapE& h0, HeapE& h1, HeapE& h2, HeapE& h3) {
-  {  // len 4 -> 3: value = h3, h3 = root, adjust(first,0,3,value)
-    const HeapE x = h3; h3 = h0;
-    if (h2.d < h1.d) { h0 = h1; if (h0.d < x.d) { h1 = h0; h0 = x; } else h1 = x; }
-    else { h0 = h2; if (h0.d < x.d) { h2 = h0; h0 = x; } else h2 = x; }
-  }
-  {  // len 3 -> 2: value = h2, h2 = root, adjust(first,0,2,value): hole -> 1
-    const HeapE x = h2; h2 = h0;
-    h0 = h1;
-    if (h0.d < x.d) { h1 = h0; h0 = x; } else h1 = x;
-  }
-  {  // len 2 -> 1
-    const HeapE x = h1; h1 = h0; h0 = x;
-  }
-}
+// libstdc++ __adjust_heap(first, 0, 4, x) + __push_heap: x replaces the root of the max-heap h0..h3
+#define HEAP4_REPLACE_ROOT(xd, xi)                                                      \
+  do {                                                                                  \
+    if (h2d < h1d) { /* larger child is 1 (ties pick 2): hole moves 0 -> 1 -> 3 */      \
+      HE_MOVE(h0, h1); HE_MOVE(h1, h3);                                                 \
+      if (h1d < (xd)) {                                                                 \
+        HE_MOVE(h3, h1);                                                                \
+        if (h0d < (xd)) { HE_MOVE(h1, h0); HE_SET(h0, xd, xi); } else HE_SET(h1, xd, xi); \
+      } else HE_SET(h3, xd, xi);                                                        \
+    } else {         /* hole moves 0 -> 2 */                                            \
+      HE_MOVE(h0, h2);                                                                  \
+      if (h0d < (xd)) { HE_MOVE(h2, h0); HE_SET(h0, xd, xi); } else HE_SET(h2, xd, xi); \
+    }                                                                                   \
+  } while (0)
 
 // ---- compaction of mask > 0 in (t, y, x) order
 __global__ void idw_count_kernel(const float* __restrict__ mask, int32_t* frame_count, int HW) {
@@ -139,14 +115,17 @@ __global__ __launch_bounds__(256) void idw_knn_kernel(const float* __restrict__ 
     acc = __fadd_rn(acc, p.w);      // fma(1, |p|^2, acc)
     return acc;
   };
-  HeapE h0, h1, h2, h3;
-  float r2;                         // d^2 of the current root (fast reject)
+  float h0d, h1d, h2d, h3d;
+  int h0i = 0, h1i = 1, h2i = 2, h3i = 3;
+  float r2;                         // fast-reject bound on d^2 (see below)
   {
-    const float d0 = dist2(pts[0]), d1 = dist2(pts[1]), d2 = dist2(pts[2]), d3 = dist2(pts[3]);
-    h0 = {sqrtf(fmaxf(d0, 0.f)), 0}; h1 = {sqrtf(fmaxf(d1, 0.f)), 1};
-    h2 = {sqrtf(fmaxf(d2, 0.f)), 2}; h3 = {sqrtf(fmaxf(d3, 0.f)), 3};
-    heap4_make(h0, h1, h2, h3);
-    r2 = h0.d * h0.d * 1.000001f + 1e-30f;
+    h0d = sqrtf(fmaxf(dist2(pts[0]), 0.f)); h1d = sqrtf(fmaxf(dist2(pts[1]), 0.f));
+    h2d = sqrtf(fmaxf(dist2(pts[2]), 0.f)); h3d = sqrtf(fmaxf(dist2(pts[3]), 0.f));
+    // __make_heap: parent = 1 (swap with child 3 unless child < parent), then parent = 0
+    if (!(h3d < h1d)) { const float td = h1d; const int ti = h1i; HE_MOVE(h1, h3); HE_SET(h3, td, ti); }
+    const float xd = h0d; const int xi = h0i;
+    HEAP4_REPLACE_ROOT(xd, xi);
+    r2 = h0d * h0d * 1.000001f + 1e-30f;
   }
   // fast reject: r2 = fl(fl(r*r)*(1+2^-20)) > r^2 exactly, so c2 >= r2 implies sqrt_rn(c2) >= r (no insert,
   // as std::partial_sort's strict comparison demands); below r2 the exact d-space test decides.
@@ -154,25 +133,37 @@ __global__ __launch_bounds__(256) void idw_knn_kernel(const float* __restrict__ 
     const float c2 = dist2(pts[j]);
     if (c2 < r2) {
       const float dc = sqrtf(fmaxf(c2, 0.f));
-      if (dc < h0.d) {
-        heap4_replace_root(h0, h1, h2, h3, HeapE{dc, j});
-        r2 = h0.d * h0.d * 1.000001f + 1e-30f;
+      if (dc < h0d) {
+        HEAP4_REPLACE_ROOT(dc, j);
+        r2 = h0d * h0d * 1.000001f + 1e-30f;
       }
     }
   }
-  heap4_sort(h0, h1, h2, h3);
+  // __sort_heap -> ascending h0..h3
+  {  // len 4 -> 3
+    const float xd = h3d; const int xi = h3i; HE_MOVE(h3, h0);
+    if (h2d < h1d) { HE_MOVE(h0, h1); if (h0d < xd) { HE_MOVE(h1, h0); HE_SET(h0, xd, xi); } else HE_SET(h1, xd, xi); }
+    else { HE_MOVE(h0, h2); if (h0d < xd) { HE_MOVE(h2, h0); HE_SET(h0, xd, xi); } else HE_SET(h2, xd, xi); }
+  }
+  {  // len 3 -> 2
+    const float xd = h2d; const int xi = h2i; HE_MOVE(h2, h0); HE_MOVE(h0, h1);
+    if (h0d < xd) { HE_MOVE(h1, h0); HE_SET(h0, xd, xi); } else HE_SET(h1, xd, xi);
+  }
+  {  // len 2 -> 1
+    const float xd = h1d; const int xi = h1i; HE_MOVE(h1, h0); HE_SET(h0, xd, xi);
+  }
   // weights (layer.py:283-290): inv = 1/(d+tau); w = inv*inv; w /= (sum + 1e-12); out = sum(v*w)
-  const float i0 = __fdiv_rn(1.f, h0.d + tau), i1 = __fdiv_rn(1.f, h1.d + tau);
-  const float i2 = __fdiv_rn(1.f, h2.d + tau), i3 = __fdiv_rn(1.f, h3.d + tau);
+  const float i0 = __fdiv_rn(1.f, h0d + tau), i1 = __fdiv_rn(1.f, h1d + tau);
+  const float i2 = __fdiv_rn(1.f, h2d + tau), i3 = __fdiv_rn(1.f, h3d + tau);
   float w0 = i0 * i0, w1 = i1 * i1, w2 = i2 * i2, w3 = i3 * i3;
   const float ws = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(w0, w1), w2), w3), 1e-12f);
   w0 = __fdiv_rn(w0, ws); w1 = __fdiv_rn(w1, ws); w2 = __fdiv_rn(w2, ws); w3 = __fdiv_rn(w3, ws);
   const int32_t* pp = pt_pos + (size_t)b * Q;
   const float* vb = vals + (size_t)b * Q;
-  const float v0 = vb[pp[h0.i]], v1 = vb[pp[h1.i]], v2 = vb[pp[h2.i]], v3 = vb[pp[h3.i]];
+  const float v0 = vb[pp[h0i]], v1 = vb[pp[h1i]], v2 = vb[pp[h2i]], v3 = vb[pp[h3i]];
   out[qo] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(v0, w0), __fmul_rn(v1, w1)), __fmul_rn(v2, w2)), __fmul_rn(v3, w3));
   if (sel_idx) {
-    *reinterpret_cast<int4*>(sel_idx + qo * 4) = make_int4(pp[h0.i], pp[h1.i], pp[h2.i], pp[h3.i]);
+    *reinterpret_cast<int4*>(sel_idx + qo * 4) = make_int4(pp[h0i], pp[h1i], pp[h2i], pp[h3i]);
     *reinterpret_cast<float4*>(sel_w + qo * 4) = make_float4(w0, w1, w2, w3);
   }
 }
