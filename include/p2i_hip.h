@@ -43,7 +43,8 @@ const char* p2i_last_error(void);
  * p2i_*_pack / p2i_doconv_fold entry points), so that the MFMA A-operand rows are contiguous.
  *
  * p2i_conv_fwd :  y = act(conv(x, W) + bias) + residual
- * p2i_conv_dgrad: dx = conv_transpose(dy * act'(y), W)      (Wd = pack with roles swapped)
+ * p2i_conv_dgrad: dx = conv_transpose(dy * act'(y), W) + dx_add   (Wd = pack with roles swapped;
+ *                 dx_add, dx-shaped or NULL, fuses the skip-path gradient of a residual block)
  * p2i_conv_wgrad: dWp[tap][cin][cout_pad] += sum_pixels x * (dy * act'(y))   (atomic fp32 adds;
  *                 caller zeroes dWp), db[cout] += sum dy*act'(y) when db != NULL.
  * dims: x (B,Cin,Ti,Hi,Wi), y (B,Cout,To,Ho,Wo); kernel (kt,kh,kw); stride (st,sh,sw);
@@ -61,7 +62,7 @@ typedef struct {
 int p2i_conv_fwd(const p2i_conv_desc* d, const float* x, const float* wp, const float* bias,
                  const float* residual, float* y, int act, void* stream);
 int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const float* y_act, int act,
-                   const float* wp_d, float* dx, void* stream);
+                   const float* wp_d, const float* dx_add, float* dx, void* stream);
 int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, const float* y_act,
                    int act, float* dwp, float* dbias, void* stream);
 

@@ -487,11 +487,11 @@ extern "C" int p2i_conv_fwd(const p2i_conv_desc* d, const float* x, const float*
 }
 
 extern "C" int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const float* y_act, int act,
-                              const float* wp_d, float* dx, void* stream) {
+                              const float* wp_d, const float* dx_add, float* dx, void* stream) {
   if (int e = check_desc(d)) return e;
   P2I_REQUIRE(dy && wp_d && dx, "null pointer");
   PatchGeom g{};
-  g.src = dy; g.src_y = y_act; g.wp = wp_d; g.bias = nullptr; g.res = nullptr; g.dst = dx; g.act_epi = P2I_ACT_NONE; g.act_pro = y_act ? act : P2I_ACT_NONE;
+  g.src = dy; g.src_y = y_act; g.wp = wp_d; g.bias = nullptr; g.res = dx_add; g.dst = dx; g.act_epi = P2I_ACT_NONE; g.act_pro = y_act ? act : P2I_ACT_NONE;
   g.B = d->B; g.Ck = d->Cout; g.Cm = d->Cin; g.CmPad = (d->Cin + 31) / 32 * 32;
   g.sT = d->To; g.sH = d->Ho; g.sW = d->Wo; g.dT = d->Ti; g.dH = d->Hi; g.dW = d->Wi;
   // one launch per parity class of the input index modulo the stride

@@ -1,0 +1,161 @@
+"""Training engine: the G/D alternating step of Trainer._train_one_epoch (train.py:240-326) on the
+HIP path, with MI355X-first memory layout: all trainable parameters of a network live in ONE flat
+fp32 buffer (parameters are views), gradients in a second flat buffer, Adam state in two more, so
+the optimiser is a single fused kernel launch and data-parallel gradient exchange is a single
+flat-bucket all-reduce over RCCL/xGMI per network per step.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+from .modules.losses import ReconstructionLoss, discriminator_loss, generator_adv_loss
+
+
+class FlatParams:
+    """Re-homes the trainable parameters of `module` into one contiguous buffer (+ grad buffer)."""
+
+    def __init__(self, module: nn.Module):
+        self.params: List[nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            off += k
+        self.n = n
+
+    def zero_grad(self):
+        self.grad.zero_()
+        off = 0
+        for p in self.params:       # autograd accumulates in place; re-attach if something replaced .grad
+            k = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + k].view(p.shape)
+            off += k
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr, betas) semantics (train.py:125-136) as one p2i_adam launch over a FlatParams."""
+
+    def __init__(self, fp: FlatParams, lr: float, betas=(0.0, 0.99), eps: float = 1e-8):
+        self.fp, self.lr, self.betas, self.eps = fp, lr, betas, eps
+        self.m = torch.zeros_like(fp.flat)
+        self.v = torch.zeros_like(fp.flat)
+        self.step_count = 0
+
+    def step(self):
+        self.step_count += 1
+        ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr, "betas": self.betas, "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+
+
+def _allreduce_mean(buf: torch.Tensor, world: int):
+    """Flat-bucket gradient exchange: sum over ranks (RCCL on GPUs, gloo in CPU tests), then 1/world."""
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    if buf.is_cuda:
+        ops.axpy_(buf, buf, 1.0 / world - 1.0)
+    else:
+        buf.mul_(1.0 / world)
+
+
+class TrainEngine:
+    def __init__(self, generator: nn.Module, discriminator: Optional[nn.Module], cfg: Dict, distributed: bool = False):
+        self.G, self.D = generator, discriminator
+        loss_cfg, opt_cfg = cfg["loss"], cfg["train"]["optimizer"]
+        self.use_gan = bool(loss_cfg.get("use_gan", 0)) and discriminator is not None
+        self.gan_type = loss_cfg.get("gan_loss", "hinge")
+        self.real_label = loss_cfg.get("target_real_label", 1.0)
+        self.fake_label = loss_cfg.get("target_fake_label", 0.0)
+        self.adv_weight = loss_cfg.get("adversarial_weight", 0.01)
+        self.rec_loss = ReconstructionLoss(k1_alpha=loss_cfg.get("k1_weight", 0.0))
+        betas = (opt_cfg.get("beta1", 0.0), opt_cfg.get("beta2", 0.99))
+        self.gp = FlatParams(self.G)
+        self.opt_g = FusedAdam(self.gp, opt_cfg["lr"], betas)
+        self.dp = self.opt_d = None
+        if self.use_gan:
+            self.dp = FlatParams(self.D)
+            self.opt_d = FusedAdam(self.dp, opt_cfg["lr"], betas)
+        self.distributed = distributed and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.distributed else 1
+        if self.distributed:
+            self.broadcast_state()
+
+    def broadcast_state(self):
+        """Rank 0's weights, spectral-norm u/v and frozen tensors to every rank, once."""
+        for net in (self.G, self.D):
+            if net is None:
+                continue
+            for t in list(net.buffers()) + [p.data for p in net.parameters() if not p.requires_grad]:
+                dist.broadcast(t, 0)
+        dist.broadcast(self.gp.flat, 0)
+        if self.dp is not None:
+            dist.broadcast(self.dp.flat, 0)
+
+    def train_step(self, frames, masked, masks) -> Dict[str, torch.Tensor]:
+        """One iteration of train.py:240-326.  Returns 0-dim DEVICE tensors (no host sync here)."""
+        self.G.train()
+        preds = self.G(masked, masks)
+        loss_g, parts = self.rec_loss(preds, frames, masks)
+        out = {"rec": loss_g.detach(), "pool": parts["pool"].tensor(), "reg": parts["reg"].tensor()}
+        if self.use_gan:
+            self.D.train()
+            for p in self.dp.params:
+                p.requires_grad_(True)
+            logits_fake = self.D(preds.detach())
+            logits_real = self.D(frames)
+            loss_d = discriminator_loss(logits_real, logits_fake, self.gan_type, self.real_label, self.fake_label)
+            self.dp.zero_grad()
+            loss_d.backward()
+            if self.distributed:
+                _allreduce_mean(self.dp.grad, self.world)
+            self.opt_d.step()
+            for p in self.dp.params:
+                p.requires_grad_(False)
+            logits_g = self.D(preds)
+            adv = generator_adv_loss(logits_g, self.adv_weight, self.gan_type, self.real_label)
+            loss_g = loss_g + adv
+            out.update(loss_d=loss_d.detach(), adv=adv.detach(), logits_real=logits_real.detach(), logits_fake=logits_fake.detach())
+        self.gp.zero_grad()
+        loss_g.backward()
+        if self.distributed:
+            _allreduce_mean(self.gp.grad, self.world)
+        self.opt_g.step()
+        if self.use_gan:
+            for p in self.dp.params:
+                p.requires_grad_(True)
+        out.update(loss_g=loss_g.detach(), preds=preds.detach())
+        return out
+
+    @torch.no_grad()
+    def eval_rec_loss(self, frames, masked, masks) -> torch.Tensor:
+        self.G.eval()
+        preds = self.G(masked, masks)
+        out3, _ = ops.recloss(preds.contiguous(), frames.contiguous(), self.rec_loss.k1_alpha)
+        return out3[2]
+
+    def checkpoint(self, epoch: int, global_step: int) -> Dict:
+        """Checkpoint dict with the reference's keys (train.py:475-485)."""
+        state = {"epoch": epoch, "global_step": global_step,
+                 "generator": {k: v.detach().clone() for k, v in self.G.state_dict().items()},
+                 "optimizer_g": self.opt_g.state_dict()}
+        if self.use_gan:
+            state["discriminator"] = {k: v.detach().clone() for k, v in self.D.state_dict().items()}
+            state["optimizer_d"] = self.opt_d.state_dict()
+        return state

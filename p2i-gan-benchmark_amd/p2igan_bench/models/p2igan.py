@@ -1,0 +1,400 @@
+"""P2I-GAN generator / discriminator on the HIP path.
+
+Drop-in for ``p2igan_bench.models.p2igan`` of the reference (p2igan.py:23-173): same constructor
+arguments, same ``forward`` signatures, same ``state_dict`` keys/shapes (so reference checkpoints
+load), same RNG consumption order at construction (so the same seed gives the same weights).
+The module tree below only HOLDS parameters; all arithmetic runs in libp2i_hip.so through one
+``torch.autograd.Function`` per network that sequences the kernels of ``p2igan_bench.ops`` and
+keeps the activations it needs for the hand-written backward.
+"""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from .. import ops
+from ..ops import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH, ConvSpec
+
+BASE_CH = 64
+
+
+# ----------------------------------------------------------------------------- parameter holders
+class _DOConvParams(nn.Module):
+    """Parameters of DOConv2d (deconv_pytorch.py:52-70): W (O, I/g, k*k), D (I, k*k, k*k), frozen D_diag."""
+
+    def __init__(self, in_ch: int, out_ch: int, ksz: int, groups: int = 1):
+        super().__init__()
+        self.in_ch, self.out_ch, self.ksz, self.groups = in_ch, out_ch, ksz, groups
+        mn = ksz * ksz
+        self.W = nn.Parameter(torch.empty(out_ch, in_ch // groups, mn))
+        init.kaiming_uniform_(self.W, a=math.sqrt(5))
+        if mn > 1:
+            self.D = nn.Parameter(torch.zeros(in_ch, mn, mn))
+            self.D_diag = nn.Parameter(torch.eye(mn).reshape(1, mn, mn).repeat(in_ch, 1, 1), requires_grad=False)
+
+    def tensors(self):
+        if self.ksz > 1:
+            return self.W, self.D, self.D_diag
+        return self.W, None, None
+
+
+class _Holder(nn.Module):
+    """`main` = ModuleList so that keys read ....main.<idx>.… like nn.Sequential in the reference."""
+
+    def __init__(self, mods: List[nn.Module]):
+        super().__init__()
+        self.main = nn.ModuleList(mods)
+
+
+def _basic_conv(in_ch, out_ch, ksz, groups=1):          # BasicConv_do, layer.py:68-94
+    return _Holder([_DOConvParams(in_ch, out_ch, ksz, groups)])
+
+
+class _EBlockParams(nn.Module):                          # EBlock / ResBlock_do, p2igan.py:176-183, layer.py:126-135
+    def __init__(self, ch: int, num_res: int):
+        super().__init__()
+        self.layers = nn.ModuleList([_Holder([_basic_conv(ch, ch, 3), _basic_conv(ch, ch, 3)]) for _ in range(num_res)])
+
+
+class _AttnParams(nn.Module):                            # AttentionBlock, layer.py:296-299
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv = nn.Conv1d(c, c, kernel_size=1)       # parameter container only
+
+
+class _InputParams(nn.Module):                           # InputBlock, layer.py:307-314
+    def __init__(self, depth: int, t: int):
+        super().__init__()
+        self.layers = nn.ModuleList([_AttnParams(t) for _ in range(depth)])
+
+
+class _UPPosParams(nn.Module):                           # UPPos, layer.py:384-390
+    def __init__(self, in_ch, out_ch, H, W):
+        super().__init__()
+        self.pos = nn.Parameter(torch.zeros(1, 1, H, W))
+        self.proj = nn.Conv2d(in_ch, out_ch, kernel_size=1, bias=True)   # parameter container only
+
+
+def _spec2d(cin, cout, k, stride=1):
+    return ConvSpec(cin, cout, (1, k, k), (1, stride, stride), (0, k // 2, k // 2))
+
+
+# ----------------------------------------------------------------------------- generator
+class P2IGenerator(nn.Module):
+    def __init__(self, config, length: int = 16, num_res: int = 4, inference: bool = False, init_weights: bool = True):
+        super().__init__()
+        data_cfg = config.get("data_loader") or config["data"]["train"]
+        self.keep = data_cfg.get("mask", {}).get("keep", 0)
+        self.H = data_cfg["h"]
+        self.W = data_cfg["w"]
+        length = data_cfg.get("sample_length", length)
+        if length != 16:
+            raise RuntimeError("P2IGenerator is hard-wired to T=16 in the reference (AttentionBlock(16), layer.py:310)")
+        self.length = length
+        self.num_res = num_res
+        self.inference = inference
+        # construction order == reference (p2igan.py:44-67) so that torch's RNG is consumed identically
+        self.input = _InputParams(depth=2, t=length)
+        self.Decoder = nn.ModuleList([_EBlockParams(BASE_CH << l, num_res) for l in range(4)])
+        self.ConvsOut = nn.ModuleList([_basic_conv(BASE_CH, length, 1, groups=4)])
+        self.UP = nn.ModuleList([
+            _UPPosParams(BASE_CH * 2, BASE_CH, self.H, self.W),
+            _UPPosParams(BASE_CH * 4, BASE_CH * 2, self.H // 2, self.W // 2),
+            _UPPosParams(BASE_CH * 8, BASE_CH * 4, self.H // 4, self.W // 4),
+        ])
+        self.Convsin = nn.ModuleList([_basic_conv(length, BASE_CH, 3, groups=4)])
+        if init_weights:
+            self.init_weights()
+        self._pnames = [n for n, _ in self.named_parameters()]
+
+    def init_weights(self, init_type: str = "kaiming", gain: float = 0.02):
+        """BaseNetwork.init_weights (layer.py:20-40): only modules exposing `.weight` are touched, i.e. the
+        AttentionBlock Conv1d and UPPos proj Conv2d; DO-Conv W keeps kaiming_uniform(a=sqrt(5))."""
+        if init_type != "kaiming":
+            raise NotImplementedError(init_type)
+        for m in [l.conv for l in self.input.layers] + [u.proj for u in self.UP]:
+            init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
+            init.constant_(m.bias.data, 0.0)
+
+    def forward(self, masked_frames, masks):
+        params = [p for _, p in self.named_parameters()]
+        return _GeneratorFn.apply(self, masked_frames, masks, *params)
+
+
+def _doconv_of(holder):      # BasicConv holder -> DOConv params
+    return holder.main[0]
+
+
+class _GeneratorFn(torch.autograd.Function):
+    """P2IGenerator.forward (p2igan.py:72-112) and its hand-sequenced backward."""
+
+    @staticmethod
+    def forward(ctx, net: P2IGenerator, masked_frames, masks, *params):
+        b, t, c, h, w = masked_frames.shape
+        if c != 1 or t != net.length:
+            raise RuntimeError(f"generator expects (B,{net.length},1,H,W), got {tuple(masked_frames.shape)}")
+        if h % 8 or w % 8:
+            raise RuntimeError("H and W must be multiples of 8")
+        need_grad = any(ctx.needs_input_grad[3:])
+        x0 = masked_frames.reshape(b, t, h, w).contiguous().float()
+        mk = masks.reshape(b, t, h, w).contiguous().float()
+        S = []                                   # saved state for backward
+        att = [l.conv for l in net.input.layers]
+        a = ops.attn_fwd(x0, att[0].weight, att[0].bias, att[1].weight, att[1].bias)
+        idw, sel = ops.idw_fwd(a, mk, tau=0.05, save=need_grad)
+        del a
+        cin = _doconv_of(net.Convsin[0])
+        wp_in = ops.doconv_fold(*cin.tensors(), BASE_CH, t, 4, 3, identity_rep=4, need_d=need_grad)
+        spec_in = _spec2d(t, BASE_CH, 3)
+        x_ = ops.conv_fwd(spec_in, idw, wp_in[0])
+        x_2 = ops.pooldup_fwd(x_)
+        x_4 = ops.pooldup_fwd(x_2)
+        x_8 = ops.pooldup_fwd(x_4)
+
+        def eblock(lvl, hcur):
+            ch = BASE_CH << lvl
+            spec = _spec2d(ch, ch, 3)
+            rec = []
+            for rb in net.Decoder[lvl].layers:
+                c1, c2 = _doconv_of(rb.main[0]), _doconv_of(rb.main[1])
+                w1 = ops.doconv_fold(*c1.tensors(), ch, ch, 1, 3, need_d=need_grad)
+                w2 = ops.doconv_fold(*c2.tensors(), ch, ch, 1, 3, need_d=need_grad)
+                y1 = ops.conv_fwd(spec, hcur, w1[0], act=ACT_RELU)
+                hn = ops.conv_fwd(spec, y1, w2[0], residual=hcur)
+                rec.append((hcur, y1, w1[1], w2[1]))
+                hcur = hn
+            return hcur, rec
+
+        def uppos(i, hcur):
+            up = net.UP[i]
+            cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
+            u = ops.upmod_fwd(hcur, up.pos)
+            wp = ops.weight_pack(up.proj.weight.reshape(cout_, cin_, 1), need_d=need_grad)
+            r = ops.conv_fwd(_spec2d(cin_, cout_, 1), u, wp[0], bias=up.proj.bias, act=ACT_RELU)
+            return r, (hcur, u, r, wp[1])
+
+        h3, rec3 = eblock(3, x_8)
+        res1, up2 = uppos(2, h3)
+        x4s = ops.axpy_(x_4.clone(), res1)                      # x_4 + res1, p2igan.py:95 (the only skip)
+        h2, rec2 = eblock(2, x4s)
+        res2, up1 = uppos(1, h2)
+        h1, rec1 = eblock(1, res2)
+        res3, up0 = uppos(0, h1)
+        h0, rec0 = eblock(0, res3)
+        cout = _doconv_of(net.ConvsOut[0])
+        wp_out = ops.doconv_fold(*cout.tensors(), t, BASE_CH, 4, 1, need_d=need_grad)
+        spec_out = _spec2d(BASE_CH, t, 1)
+        z = ops.conv_fwd(spec_out, h0, wp_out[0], act=ACT_TANH)
+        if need_grad:
+            ctx.net = net
+            ctx.S = dict(x0=x0, idw=idw, sel=sel, wp_in_d=wp_in[1], x_=x_, x_2=x_2, x_4=x_4,
+                         rec=[rec0, rec1, rec2, rec3], up=[up0, up1, up2], h0=h0, z=z, wp_out_d=wp_out[1],
+                         shape=(b, t, h, w))
+        return z.view(b, t, c, h, w)
+
+    @staticmethod
+    def backward(ctx, dout):
+        net, S = ctx.net, ctx.S
+        b, t, h, w = S["shape"]
+        grads = {}
+        dz = dout.reshape(b, t, h, w).contiguous().float()
+        # ---- ConvsOut (grouped 1x1, dense-lowered) + tanh
+        spec_out = _spec2d(BASE_CH, t, 1)
+        cout = _doconv_of(net.ConvsOut[0])
+        dwp, _ = ops.conv_wgrad(spec_out, S["h0"], dz, S["z"], ACT_TANH)
+        grads[id(cout.W)], _ = ops.doconv_fold_bwd(dwp, *cout.tensors(), t, BASE_CH, 4, 1)
+        dh = ops.conv_dgrad(spec_out, dz, S["wp_out_d"], tuple(S["h0"].shape), S["z"], ACT_TANH)
+
+        def eblock_bwd(lvl, dh):
+            ch = BASE_CH << lvl
+            spec = _spec2d(ch, ch, 3)
+            blocks = net.Decoder[lvl].layers
+            for rb, (hin, y1, w1d, w2d) in zip(reversed(list(blocks)), reversed(S["rec"][lvl])):
+                c1, c2 = _doconv_of(rb.main[0]), _doconv_of(rb.main[1])
+                dwp2, _ = ops.conv_wgrad(spec, y1, dh)
+                grads[id(c2.W)], grads[id(c2.D)] = ops.doconv_fold_bwd(dwp2, *c2.tensors(), ch, ch, 1, 3)
+                dy1 = ops.conv_dgrad(spec, dh, w2d, tuple(y1.shape))
+                dwp1, _ = ops.conv_wgrad(spec, hin, dy1, y1, ACT_RELU)
+                grads[id(c1.W)], grads[id(c1.D)] = ops.doconv_fold_bwd(dwp1, *c1.tensors(), ch, ch, 1, 3)
+                dh = ops.conv_dgrad(spec, dy1, w1d, tuple(hin.shape), y1, ACT_RELU, add=dh)   # + skip path
+            return dh
+
+        def uppos_bwd(i, dr):
+            up = net.UP[i]
+            hin, u, r, wpd = S["up"][i]
+            cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
+            spec = _spec2d(cin_, cout_, 1)
+            dwp, db = ops.conv_wgrad(spec, u, dr, r, ACT_RELU, want_bias=True)
+            grads[id(up.proj.weight)] = ops.weight_unpack_grad(dwp, up.proj.weight.reshape(cout_, cin_, 1)).reshape(up.proj.weight.shape)
+            grads[id(up.proj.bias)] = db
+            du = ops.conv_dgrad(spec, dr, wpd, tuple(u.shape), r, ACT_RELU)
+            dx, dpos = ops.upmod_bwd(hin, up.pos, du)
+            grads[id(up.pos)] = dpos
+            return dx
+
+        dh = eblock_bwd(0, dh)
+        dh = uppos_bwd(0, dh)
+        dh = eblock_bwd(1, dh)
+        dh = uppos_bwd(1, dh)
+        dx4s = eblock_bwd(2, dh)              # grad of x_4 + res1: flows to both terms
+        dh = uppos_bwd(2, dx4s)
+        dx8 = eblock_bwd(3, dh)
+        dx4 = ops.axpy_(ops.pooldup_bwd(S["x_4"], dx8), dx4s)
+        dx2 = ops.pooldup_bwd(S["x_2"], dx4)
+        dx_ = ops.pooldup_bwd(S["x_"], dx2)
+        # ---- Convsin (grouped 3x3 + repeat_interleave skip, dense-lowered with centre identity)
+        spec_in = _spec2d(t, BASE_CH, 3)
+        cin = _doconv_of(net.Convsin[0])
+        dwp, _ = ops.conv_wgrad(spec_in, S["idw"], dx_)
+        grads[id(cin.W)], grads[id(cin.D)] = ops.doconv_fold_bwd(dwp, *cin.tensors(), BASE_CH, t, 4, 3)
+        didw = ops.conv_dgrad(spec_in, dx_, S["wp_in_d"], tuple(S["idw"].shape))
+        da = ops.idw_bwd(didw, S["sel"])
+        att = [l.conv for l in net.input.layers]
+        g = ops.attn_bwd(S["x0"], att[0].weight, att[0].bias, att[1].weight, att[1].bias, da)
+        for prm, gr in zip((att[0].weight, att[0].bias, att[1].weight, att[1].bias), g):
+            grads[id(prm)] = gr.reshape(prm.shape)
+        out = []
+        for (name, prm), need in zip(net.named_parameters(), ctx.needs_input_grad[3:]):
+            out.append(grads.get(id(prm)) if need else None)
+        ctx.S = None
+        return (None, None, None, *out)
+
+
+# ----------------------------------------------------------------------------- discriminator
+D2D_LAYERS = [(0, 64, 1), (2, 128, 2), (4, 256, 2), (6, 256, 1), (8, 1, 1)]           # p2igan.py:120-130
+D3D_LAYERS = [(0, 32, 3, (1, 2, 2), 1), (2, 64, 3, (1, 2, 2), 1), (4, 128, 3, (1, 2, 2), 1),
+              (6, 128, 3, (2, 1, 1), 1), (8, 1, 1, (1, 1, 1), 0)]                      # p2igan.py:132-142
+
+
+class P2IDiscriminator(nn.Module):
+    def __init__(self, in_channels: int = 16, init_weights: bool = True):
+        super().__init__()
+        self.in_channels = in_channels
+        sn = nn.utils.spectral_norm            # parameter containers (weight_orig / weight_u / weight_v / bias)
+        mods, cin = [], in_channels
+        for n, (_, cout, s) in enumerate(D2D_LAYERS):
+            mods.append(sn(nn.Conv2d(cin, cout, kernel_size=3, stride=s, padding=1)))
+            if n < 4:
+                mods.append(nn.LeakyReLU(0.2, True))
+            cin = cout
+        self.d2d = nn.Sequential(*mods)
+        mods, cin = [], 1
+        for n, (_, cout, k, st, p) in enumerate(D3D_LAYERS):
+            mods.append(sn(nn.Conv3d(cin, cout, kernel_size=k, stride=st, padding=p)))
+            if n < 4:
+                mods.append(nn.LeakyReLU(0.2, True))
+            cin = cout
+        self.d3d = nn.Sequential(*mods)
+        self.alpha2d = nn.Parameter(torch.tensor(0.0))
+        self.alpha3d = nn.Parameter(torch.tensor(0.0))      # declared but unused by forward (p2igan.py:145,170)
+        if init_weights:
+            self.init_weights()
+        self.specs2d, cin = [], in_channels
+        for _, cout, s in D2D_LAYERS:
+            self.specs2d.append(_spec2d(cin, cout, 3, s))
+            cin = cout
+        self.specs3d, cin = [], 1
+        for _, cout, k, st, p in D3D_LAYERS:
+            self.specs3d.append(ConvSpec(cin, cout, (k, k, k), st, (p, p, p)))
+            cin = cout
+
+    def init_weights(self):
+        """p2igan.py:150-155 (writes through the spectral-norm `weight` alias into weight_orig)."""
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+                init.kaiming_normal_(m.weight_orig.data, a=0.2, nonlinearity="leaky_relu")
+                if m.bias is not None:
+                    init.zeros_(m.bias)
+
+    def layers(self):
+        l2 = [self.d2d[i] for i, _, _ in D2D_LAYERS]
+        l3 = [self.d3d[i] for i, *_ in D3D_LAYERS]
+        return l2, l3
+
+    def forward(self, x):
+        l2, l3 = self.layers()
+        params = []
+        for m in l2 + l3:
+            params += [m.weight_orig, m.bias]
+        params.append(self.alpha2d)
+        return _DiscriminatorFn.apply(self, x, *params)
+
+
+class _DiscriminatorFn(torch.autograd.Function):
+    """P2IDiscriminator.forward (p2igan.py:157-173) incl. spectral-norm power iteration, and backward."""
+
+    @staticmethod
+    def forward(ctx, net: P2IDiscriminator, x, *params):
+        b, t, c, h, w = x.shape
+        if c * t != net.in_channels:
+            raise RuntimeError(f"discriminator expects {net.in_channels} frames, got {t}x{c}")
+        xin = x.contiguous().float()
+        l2, l3 = net.layers()
+        need_x = ctx.needs_input_grad[1]
+        need_p = any(ctx.needs_input_grad[2:])
+        training = net.training
+
+        def branch(layers, specs, inp):
+            recs, cur = [], inp
+            for n, (m, spec) in enumerate(zip(layers, specs)):
+                wo = m.weight_orig
+                sigma = ops.spectral_norm(wo, m.weight_u, m.weight_v, training)
+                wflat = wo.reshape(wo.shape[0], wo.shape[1], -1)
+                wp_f, wp_d = ops.weight_pack(wflat, sigma, need_d=(need_x or need_p))
+                act = ACT_LEAKY if n < 4 else ACT_NONE
+                y = ops.conv_fwd(spec, cur, wp_f, bias=m.bias, act=act)
+                recs.append(dict(x=cur, y=y, wp_d=wp_d, sigma=sigma, act=act,
+                                 u=m.weight_u.clone() if need_p else None, v=m.weight_v.clone() if need_p else None))
+                cur = y
+            return cur, recs
+
+        o2, r2 = branch(l2, net.specs2d, xin.view(b, t * c, h, w))
+        o3, r3 = branch(l3, net.specs3d, xin.view(b, c, t, h, w))      # permute(0,2,1,3,4) with c == 1 is a view
+        fused = ops.dtail_fwd(o2, o3, net.alpha2d.reshape(1))
+        if need_x or need_p:
+            ctx.net, ctx.r2, ctx.r3, ctx.xshape = net, r2, r3, (b, t, c, h, w)
+        return fused
+
+    @staticmethod
+    def backward(ctx, dfused):
+        net, r2, r3 = ctx.net, ctx.r2, ctx.r3
+        b, t, c, h, w = ctx.xshape
+        l2, l3 = net.layers()
+        need_x = ctx.needs_input_grad[1]
+        needs = ctx.needs_input_grad[2:]
+        nl = len(l2) + len(l3)
+        need_alpha = needs[2 * nl]
+        o2, o3 = r2[-1]["y"], r3[-1]["y"]
+        d2, d3, da = ops.dtail_bwd(o2, tuple(o3.shape), net.alpha2d.reshape(1), dfused.contiguous().float(), need_alpha=need_alpha)
+        gw, gb = {}, {}
+
+        def branch_bwd(layers, specs, recs, dy, base, first_add=None):
+            for n in reversed(range(len(layers))):
+                m, spec, rc = layers[n], specs[n], recs[n]
+                y_act = rc["y"] if rc["act"] != ACT_NONE else None
+                if needs[2 * (base + n)] or needs[2 * (base + n) + 1]:
+                    dwp, db = ops.conv_wgrad(spec, rc["x"], dy, y_act, rc["act"], want_bias=True)
+                    wo = m.weight_orig
+                    wflat = wo.reshape(wo.shape[0], wo.shape[1], -1)
+                    gw[base + n] = ops.weight_unpack_grad(dwp, wflat, wflat, rc["sigma"], rc["u"], rc["v"]).reshape(wo.shape)
+                    gb[base + n] = db
+                if n > 0 or need_x:
+                    dy = ops.conv_dgrad(spec, dy, rc["wp_d"], tuple(rc["x"].shape), y_act, rc["act"],
+                                        add=first_add if n == 0 else None)
+                else:
+                    dy = None
+            return dy
+
+        dx3 = branch_bwd(l3, net.specs3d, r3, d3, len(l2))
+        dx = branch_bwd(l2, net.specs2d, r2, d2, 0, first_add=dx3.view(b, t * c, h, w) if dx3 is not None else None)
+        out = []
+        for i in range(nl):
+            out.append(gw.get(i) if needs[2 * i] else None)
+            out.append(gb.get(i) if needs[2 * i + 1] else None)
+        out.append(da.reshape(net.alpha2d.shape) if need_alpha else None)
+        ctx.r2 = ctx.r3 = None
+        return (None, dx.view(b, t, c, h, w) if need_x else None, *out)

@@ -90,7 +90,7 @@ def conv_fwd(spec: ConvSpec, x, wp_f, bias=None, residual=None, act=ACT_NONE, ou
     return y
 
 
-def conv_dgrad(spec: ConvSpec, dy, wp_d, in_shape, y_act=None, act=ACT_NONE):
+def conv_dgrad(spec: ConvSpec, dy, wp_d, in_shape, y_act=None, act=ACT_NONE, add=None):
     """dx for input of shape in_shape; if y_act is given dy is first multiplied by act'(y_act)."""
     lib = _hip.load()
     if len(in_shape) == 4:
@@ -104,10 +104,12 @@ def conv_dgrad(spec: ConvSpec, dy, wp_d, in_shape, y_act=None, act=ACT_NONE):
         raise RuntimeError(f"conv_dgrad: shape mismatch dy={tuple(dy.shape)} expected {eshape}")
     if y_act is not None and y_act.shape != dy.shape:
         raise RuntimeError("conv_dgrad: y_act shape mismatch")
+    if add is not None and tuple(add.shape) != tuple(in_shape):
+        raise RuntimeError("conv_dgrad: add shape mismatch")
     dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
-    _chk(dy, wp_d, y_act, dx)
+    _chk(dy, wp_d, y_act, dx, add)
     d = spec.desc(b, t, h, w)
-    _hip.check(lib.p2i_conv_dgrad(d, _ptr(dy), _ptr(y_act), act, _ptr(wp_d), _ptr(dx), _stream()), "p2i_conv_dgrad")
+    _hip.check(lib.p2i_conv_dgrad(d, _ptr(dy), _ptr(y_act), act, _ptr(wp_d), _ptr(add), _ptr(dx), _stream()), "p2i_conv_dgrad")
     return dx
 
 

@@ -218,7 +218,25 @@ def case_idw():
     print("idw done")
 
 
+def case_init():
+    """state_dict keys/shapes and checksums of the reference's own initialisation for seed 1234 (32x32)."""
+    import json
+    torch.manual_seed(1234)
+    G = build_generator(cfg_for(32, 32))
+    D = build_discriminator(cfg_for(32, 32))
+    rec = {"G": [[k, list(v.shape), float(v.double().sum()), float(v.double().abs().sum())] for k, v in G.state_dict().items()],
+           "D": [[k, list(v.shape), float(v.double().sum()), float(v.double().abs().sum())] for k, v in D.state_dict().items()],
+           "G_trainable": [n for n, p in G.named_parameters() if p.requires_grad],
+           "D_trainable": [n for n, p in D.named_parameters() if p.requires_grad]}
+    with open(os.path.join(OUT, "init_32.json"), "w") as f:
+        json.dump(rec, f)
+    print("init: G keys", len(rec["G"]), "D keys", len(rec["D"]))
+
+
 if __name__ == "__main__":
+    case_init()
+    if "--init-only" in sys.argv:
+        sys.exit(0)
     case_idw()
     case_e2e_32()
     case_eval_and_infer_32()

@@ -1,0 +1,43 @@
+"""Drop-in surface on CPU: construction API, state_dict keys/shapes and seed-for-seed identical
+initialisation with the reference (fixture tests/golden/init_32.json captured from the reference)."""
+import json
+import os
+
+import torch
+
+from conftest import GOLDEN
+
+CFG = {"model": {"name": "p2igan", "in_channels": 1}, "data": {"train": {"h": 32, "w": 32, "sample_length": 16}}}
+
+
+def test_state_dict_and_init_match_reference():
+    from p2igan_bench.models import build_discriminator, build_generator
+    ref = json.load(open(os.path.join(GOLDEN, "init_32.json")))
+    torch.manual_seed(1234)
+    G = build_generator(CFG)
+    D = build_discriminator(CFG)
+    for net, key in ((G, "G"), (D, "D")):
+        sd = net.state_dict()
+        assert list(sd.keys()) == [r[0] for r in ref[key]]
+        for (k, shape, s, a) in ref[key]:
+            assert list(sd[k].shape) == shape, k
+            assert abs(float(sd[k].double().sum()) - s) <= 1e-9 * max(1.0, a), k
+            assert abs(float(sd[k].double().abs().sum()) - a) <= 1e-9 * max(1.0, a), k
+    assert [n for n, p in G.named_parameters() if p.requires_grad] == ref["G_trainable"]
+    assert [n for n, p in D.named_parameters() if p.requires_grad] == ref["D_trainable"]
+
+
+def test_seeded_recipe_loads_strictly():
+    from p2igan_bench.models import build_discriminator, build_generator
+    from p2igan_bench.utils import seeded
+    G = build_generator(CFG)
+    D = build_discriminator(CFG)
+    G.load_state_dict(seeded.seeded_generator_state(32, 32), strict=True)
+    D.load_state_dict(seeded.seeded_discriminator_state(), strict=True)
+
+
+def test_other_model_families_are_rejected():
+    import pytest
+    from p2igan_bench.models import build_generator
+    with pytest.raises(NotImplementedError):
+        build_generator({"model": {"name": "dk"}, "data": {"train": {"h": 32, "w": 32}}})

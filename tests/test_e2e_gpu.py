@@ -1,0 +1,159 @@
+"""End-to-end parity on the GPU: generator / discriminator / losses / full G+D train steps through
+the drop-in API vs (a) golden vectors captured from the genuine reference and (b) the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4          # north_star: 1e-4 relative (to max-abs), fp32
+
+CFG32 = {"model": {"name": "p2igan", "in_channels": 1}, "data": {"train": {"h": 32, "w": 32, "sample_length": 16}},
+         "loss": {"use_gan": 1, "gan_loss": "hinge", "k1_weight": 0.05, "adversarial_weight": 0.01},
+         "train": {"optimizer": {"lr": 1e-4, "beta1": 0.0, "beta2": 0.99}}}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from p2igan_bench import _hip
+    _hip.load()
+    return torch.device("cuda:0")
+
+
+def _batch32():
+    from p2igan_bench.utils import seeded
+    h = w = 32
+    m0 = seeded.gauge_mask(h, w, 20)
+    m1 = seeded.block_mask(h, w, 4)
+    f0, k0, mk0 = seeded.synthetic_batch(1, 16, h, w, m0, seed=2024)
+    f1, k1, mk1 = seeded.synthetic_batch(1, 16, h, w, m1, seed=3024)
+    return torch.cat([f0, f1]), torch.cat([k0, k1]), torch.cat([mk0, mk1])
+
+
+def _build(dev, h=32, w=32):
+    from p2igan_bench.models import build_discriminator, build_generator
+    from p2igan_bench.utils import seeded
+    cfg = dict(CFG32, data={"train": {"h": h, "w": w, "sample_length": 16}})
+    G = build_generator(cfg).to(dev)
+    D = build_discriminator(cfg).to(dev)
+    G.load_state_dict(seeded.seeded_generator_state(h, w))
+    D.load_state_dict(seeded.seeded_discriminator_state())
+    return cfg, G, D
+
+
+def test_train_steps_match_reference_golden(dev, golden):
+    from p2igan_bench.engine import TrainEngine
+    g = golden("e2e_32.npz")
+    cfg, G, D = _build(dev)
+    eng = TrainEngine(G, D, cfg)
+    frames, masked, masks = [t.to(dev) for t in _batch32()]
+    r = eng.train_step(frames, masked, masks)
+    assert rel_err(r["preds"].cpu().numpy(), g["preds"]) < TOL
+    assert rel_err(r["logits_fake"].cpu().numpy(), g["logits_fake"]) < TOL
+    assert rel_err(r["logits_real"].cpu().numpy(), g["logits_real"]) < TOL
+    for k in ("loss_g", "loss_d", "adv", "pool", "reg"):
+        assert abs(float(r[k]) - float(g[k])) <= TOL * abs(float(g[k])), k
+    # gradients of step 0 are still in the flat grad buffers
+    gparams = dict(G.named_parameters())
+    dparams = dict(D.named_parameters())
+    for k in g.files:
+        if k.startswith("ggradnorm/"):
+            n = k.split("/", 1)[1]
+            assert abs(float(gparams[n].grad.norm()) - float(g[k])) <= 1e-3 * float(g[k]) + 1e-7, k
+        if k.startswith("ggrad/"):
+            assert rel_err(gparams[k.split("/", 1)[1]].grad.cpu().numpy(), g[k]) < 1e-3, k
+    # D grads were overwritten by nothing after the D step (G step does not touch them)
+    for k in g.files:
+        if k.startswith("dgradnorm/"):
+            n = k.split("/", 1)[1]
+            assert abs(float(dparams[n].grad.norm()) - float(g[k])) <= 1e-3 * float(g[k]) + 1e-7, k
+        if k.startswith("dgrad/"):
+            assert rel_err(dparams[k.split("/", 1)[1]].grad.cpu().numpy(), g[k]) < 1e-3, k
+    assert float(dparams["alpha3d"].grad.abs().sum()) == 0.0      # never receives a gradient (p2igan.py:145,170)
+    gsd, dsd = G.state_dict(), D.state_dict()
+    for k in g.files:
+        if k.startswith("g1sum/"):
+            assert abs(float(gsd[k[6:]].double().sum()) - float(g[k])) <= 2e-3 * max(1.0, abs(float(g[k]))), k
+        if k.startswith("d1sum/"):
+            assert abs(float(dsd[k[6:]].double().sum()) - float(g[k])) <= 2e-3 * max(1.0, abs(float(g[k]))), k
+    assert rel_err(dsd["d3d.0.weight_u"].cpu().numpy(), g["d1/d3d.0.weight_u"]) < 1e-4
+    assert rel_err(dsd["d2d.6.weight_v"].cpu().numpy(), g["d1/d2d.6.weight_v"]) < 1e-4
+    r = eng.train_step(frames, masked, masks)
+    assert abs(float(r["loss_g"]) - float(g["loss_g_step1"])) < 1e-3 * abs(float(g["loss_g_step1"]))
+    r = eng.train_step(frames, masked, masks)
+    assert abs(float(r["loss_g"]) - float(g["loss_g_step2"])) < 1e-3 * abs(float(g["loss_g_step2"]))
+    assert abs(float(r["loss_d"]) - float(g["loss_d_step2"])) < 1e-3 * abs(float(g["loss_d_step2"]))
+    assert rel_err(G.state_dict()["Convsin.0.main.0.W"].cpu().numpy(), g["g3/Convsin.0.main.0.W"]) < 1e-3
+    assert rel_err(D.state_dict()["d2d.2.bias"].cpu().numpy(), g["d3/d2d.2.bias"]) < 1e-3
+
+
+def test_intermediate_taps_match_oracle(dev):
+    """Stage-by-stage against the CPU oracle on the same batch (localises a regression)."""
+    from oracle import p2i_oracle as orc
+    from p2igan_bench import ops
+    from p2igan_bench.utils import seeded
+    cfg, G, D = _build(dev)
+    frames, masked, masks = _batch32()
+    taps = {}
+    with torch.no_grad():
+        ref = orc.generator_forward(seeded.seeded_generator_state(32, 32), masked, masks, taps)
+        out = G(masked.to(dev), masks.to(dev))
+        dtaps = {}
+        lref = orc.discriminator_forward(seeded.seeded_discriminator_state(), frames, training=True, taps=dtaps)
+        D.train()
+        lg = D(frames.to(dev))
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < TOL
+    assert rel_err(lg.cpu().numpy(), lref.numpy()) < TOL
+    # eval mode does not move u, v
+    D.eval()
+    u0 = D.d2d[0].weight_u.clone()
+    with torch.no_grad():
+        D(frames.to(dev))
+    assert torch.equal(u0, D.d2d[0].weight_u)
+
+
+def test_generator_128_matches_reference_golden(dev, golden):
+    from p2igan_bench.utils import seeded
+    g = golden("g_128.npz")
+    cfg, G, _ = _build(dev, 128, 128)
+    frames, masked, masks = seeded.synthetic_batch(1, 16, 128, 128, seeded.gauge_mask(128, 128, 79))
+    G.eval()
+    with torch.no_grad():
+        preds = G(masked.to(dev), masks.to(dev))
+    assert rel_err(preds.cpu().numpy()[0, :, 0, ::3, ::3], g["preds_s3"]) < TOL
+    assert abs(float(preds.double().sum()) - float(g["preds_sum"])) < 1e-4 * float(g["preds_abs_sum"])
+
+
+def test_empty_mask_and_eval_logits(dev, golden):
+    from p2igan_bench.utils import seeded
+    g = golden("infer_32.npz")
+    cfg, G, D = _build(dev)
+    h = w = 32
+    ev = seeded.synthetic_event(40, h, w, seed=99).float() / 255.0
+    frames = ev.reshape(1, 40, 1, h, w)[:, :16].contiguous()
+    G.eval(); D.eval()
+    with torch.no_grad():
+        z = G(torch.zeros_like(frames).to(dev), torch.zeros_like(frames).to(dev))
+        logits = D(frames.to(dev))
+    assert rel_err(z.cpu().numpy(), g["empty"]) < TOL
+    assert rel_err(logits.cpu().numpy(), g["logits_eval"]) < TOL
+
+
+def test_full_size_properties(dev):
+    """Config A size (B=2,16,128,128): size-independent properties — determinism of the forward,
+    batch independence (sample b's output does not depend on its batch-mates), tanh range."""
+    from p2igan_bench.utils import seeded
+    cfg, G, D = _build(dev, 128, 128)
+    m = seeded.gauge_mask(128, 128, 79)
+    f, k, mk = seeded.synthetic_batch(2, 16, 128, 128, m)
+    G.eval()
+    with torch.no_grad():
+        a = G(k.to(dev), mk.to(dev))
+        b = G(k.to(dev), mk.to(dev))
+        c = G(k[1:].to(dev), mk[1:].to(dev))
+    assert torch.equal(a, b)
+    assert rel_err(c.cpu().numpy(), a[1:].cpu().numpy()) < 1e-5
+    assert float(a.abs().max()) <= 1.0
