@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Headline benchmark: P2I-GAN train frames/s on synthetic (B,16,1,128,128) events (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one full G+D training iteration (train.py:240-326: G fwd, rec loss, D fwd x2 + D bwd +
+Adam-D, D fwd + adv loss, G bwd through D, Adam-G) on one batch already resident in HBM.
+Per-GPU batch is fixed (weak scaling): configs[1] = B=8 on 1 GPU, configs[2] = 8 per GPU on 8 GPUs.
+Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "p2i-gan-benchmark_amd"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+T, H, W = 16, 128, 128
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+GFLOP_PER_SAMPLE_STEP = 183.97     # algorithmic conv FLOPs of one full train step
+
+
+def make_cfg():
+    return {"seed": 2024, "model": {"name": "p2igan", "in_channels": 1},
+            "data": {"train": {"h": H, "w": W, "sample_length": T}},
+            "loss": {"use_gan": 1, "gan_loss": "hinge", "k1_weight": 0.05, "adversarial_weight": 0.01},
+            "train": {"optimizer": {"lr": 1e-4, "beta1": 0.0, "beta2": 0.99}}}
+
+
+def cpu_baseline(batch, steps, threads):
+    """The CPU oracle (port of the reference step; reference source does not travel) timed on host cores."""
+    from oracle import p2i_oracle as orc
+    from p2igan_bench.utils import seeded
+    torch.set_num_threads(threads)
+    orc.IDW_IMPL = "torch"         # time what the reference executes (cdist + topk), not the pinned C checker
+    cfg = make_cfg()
+    st = orc.TrainState(seeded.seeded_generator_state(H, W, mode="init"), seeded.seeded_discriminator_state(mode="init"),
+                        cfg["loss"], cfg["train"]["optimizer"])
+    frames, masked, masks = seeded.synthetic_batch(batch, T, H, W, seeded.gauge_mask(H, W, 79))
+    st.step(frames, masked, masks)                    # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.step(frames, masked, masks)
+    dt = (time.perf_counter() - t0) / steps
+    orc.IDW_IMPL = "c"
+    return {"value": batch * T / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} full train steps at B={batch} (T=16,128x128, 79 gauges/frame) after 1 warm-up, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (configs[1]: 8)")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from p2igan_bench import _hip, ops
+    from p2igan_bench.engine import TrainEngine
+    from p2igan_bench.models import build_discriminator, build_generator
+    from p2igan_bench.utils import seeded
+    _hip.load()
+    cfg = make_cfg()
+    torch.manual_seed(cfg["seed"])                     # reference init (train.py:78-82,121-122), random weights
+    G = build_generator(cfg).to(dev)
+    D = build_discriminator(cfg).to(dev)
+    eng = TrainEngine(G, D, cfg, distributed=world > 1)
+    B = args.batch
+    mask = seeded.gauge_mask(H, W, 79)
+    frames, masked, masks = [t.to(dev) for t in seeded.synthetic_batch(B, T, H, W, mask, seed=2024 + 1000 * rank)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.train_step(frames, masked, masks)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step(frames, masked, masks)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * T * args.steps / dt
+
+    roofline = None
+    extra = {}
+    if rank == 0 and not args.no_roofline:
+        # instrumented pass (HIP events around every conv-engine launch on the launch stream); separate from
+        # the timed region above so that `value` is unperturbed
+        ops.PROFILE = ops.KernelProfile()
+        nprof = max(2, min(5, args.steps))
+        for _ in range(nprof):
+            eng.train_step(frames, masked, masks)
+        summ = ops.PROFILE.summary()
+        ops.PROFILE = None
+        gemm = {k: v for k, v in summ.items() if k.startswith("patch_gemm_kernel<")}
+        dom = max(gemm, key=lambda k: gemm[k]["seconds"])
+        d = gemm[dom]
+        ach = d["flops"] / d["seconds"] / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get(dom)
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "avg_launch_us": round(d["seconds"] / d["launches"] * 1e6, 2),
+                    "flops_per_launch": d["flops"] / d["launches"], "launches_per_step": d["launches"] / nprof}
+        tot_s = sum(v["seconds"] for v in summ.values())
+        tot_f = sum(v["flops"] for v in summ.values())
+        extra["conv_engine_all"] = {"tflops": round(tot_f / tot_s / 1e12, 2), "ms_per_step": round(tot_s / nprof * 1e3, 2),
+                                    "frac_of_peak": round(tot_f / tot_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+        extra["kernels"] = {k: {"ms_per_step": round(v["seconds"] / nprof * 1e3, 3), "tflops": round(v["flops"] / v["seconds"] / 1e12, 2)}
+                            for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])}
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = min(os.cpu_count() or 1, int(os.environ.get("P2I_CPU_THREADS", "16")))
+        cpu = cpu_baseline(args.cpu_batch, args.cpu_steps, threads)
+
+    if rank == 0:
+        line = {"metric": "train frames/sec (128x128x16)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "configs[1]: p2igan_gan_baseline train step, hinge GAN, B=%d per GPU, T=16, 128x128, 79 gauge points/frame" % B,
+                           "global_batch": B * world, "parallelism": "dp%d" % world},
+                "step_tflops": round(GFLOP_PER_SAMPLE_STEP * B * world / (ms_per_step * 1e-3) / 1e3, 2),
+                "roofline": roofline, "cpu_baseline": cpu}
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,9 @@ int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const float* y_act, 
                    const float* wp_d, const float* dx_add, float* dx, void* stream);
 int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, const float* y_act,
                    int act, float* dwp, float* dbias, void* stream);
+/* tile plan {MB, NPIX, WAVES_M, CK} of the calling thread's most recent fwd/dgrad launch (names the
+ * patch_gemm_kernel<MB,NPIX,WAVES_M,CK> instance for profiling; bench.py's roofline uses it) */
+int p2i_conv_last_plan(int* out4);
 
 /* ------------------------------------------------------------------ weight preparation
  * p2i_doconv_fold_fwd: DoW = einsum('ims,ois->oim', D + D_diag, W.reshape(O/g, I, 9)) with the

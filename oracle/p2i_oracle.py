@@ -20,6 +20,9 @@ Params = Dict[str, torch.Tensor]
 BASE_CH = 64          # p2igan.py:46
 NUM_RES = 4           # p2igan.py:24
 IDW_K, IDW_RHO, IDW_TAU, IDW_CHUNK = 4, 2.0, 0.05, 16384   # p2igan.py:44
+# "c": pinned host-independent selection (parity checks); "torch": literal cdist/topk as the reference
+# executes it (used when TIMING the CPU baseline, bench.py)
+IDW_IMPL = "c"
 
 
 # --------------------------------------------------------------------------- DO-Conv
@@ -170,7 +173,8 @@ def input_block(p: Params, frames: torch.Tensor, mask: torch.Tensor) -> torch.Te
             outs.append(torch.zeros(1, D, H, W))
             continue
         vals = x[b][tz, ty, tx]
-        outs.append(idw_3d_knn(pts, vals, (D, H, W)).unsqueeze(0))
+        fn = idw_3d_knn if IDW_IMPL == "c" else idw_3d_knn_torch
+        outs.append(fn(pts, vals, (D, H, W)).unsqueeze(0))
     return torch.cat(outs, dim=0)
 
 

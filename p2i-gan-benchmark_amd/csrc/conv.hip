@@ -379,6 +379,8 @@ struct ClassSpec {
   int dt[MAX_TAPS], dh[MAX_TAPS], dw[MAX_TAPS];
 };
 
+static thread_local int g_last_plan[4] = {0, 0, 0, 0};
+
 static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
   g.nT = cs.nT; g.nH = cs.nH; g.nW = cs.nW;
   g.mT = cs.mT; g.mH = cs.mH; g.mW = cs.mW;
@@ -440,6 +442,7 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
     g.ntt = ceil_div(cs.nT, jt); g.nth = ceil_div(cs.nH, jh); g.ntw = ceil_div(cs.nW, jw);
     const int ntb = ceil_div(g.B, jb);
     dim3 grid((unsigned)(ntb * g.ntt * g.nth * g.ntw), (unsigned)ceil_div(g.Cm, c.MB));
+    g_last_plan[0] = c.MB; g_last_plan[1] = c.NPIX; g_last_plan[2] = c.WM; g_last_plan[3] = c.CK;
     return dispatch_patch(c, g, grid, lds, s);
   }
   set_error("conv tile selection failed");
@@ -463,6 +466,12 @@ static int check_desc(const p2i_conv_desc* d) {
 }  // namespace p2i
 
 using namespace p2i;
+
+extern "C" int p2i_conv_last_plan(int* out4) {
+  if (!out4) return P2I_EINVAL;
+  for (int i = 0; i < 4; ++i) out4[i] = g_last_plan[i];
+  return P2I_OK;
+}
 
 extern "C" int p2i_conv_fwd(const p2i_conv_desc* d, const float* x, const float* wp, const float* bias,
                             const float* residual, float* y, int act, void* stream) {

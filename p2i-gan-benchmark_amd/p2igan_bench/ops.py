@@ -33,6 +33,52 @@ def _chk(*ts):
             raise RuntimeError(f"unsupported dtype {t.dtype}")
 
 
+class KernelProfile:
+    """Optional live timing of the conv-engine launches with HIP events on the launch stream
+    (torch's current stream).  Used by bench.py's instrumented pass for the roofline figure; off
+    by default so that the measured throughput is unperturbed."""
+
+    def __init__(self):
+        self.records = []            # (kernel key, algorithmic flops, start event, end event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, e0, e1 in self.records:
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += flops
+        return {k: {"launches": v[0], "seconds": v[1], "flops": v[2]} for k, v in agg.items()}
+
+
+PROFILE: Optional[KernelProfile] = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, kind, spec, desc, stride1):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    flops = 2.0 * desc.B * desc.Cout * desc.Cin * spec.ntaps * desc.To * desc.Ho * desc.Wo
+    if kind == "wgrad":
+        key = "wgrad_kernel<64>"
+    else:
+        import ctypes
+        plan = (ctypes.c_int * 4)()
+        _hip.load().p2i_conv_last_plan(plan)
+        key = "patch_gemm_kernel<%d,%d,%d,%d>" % tuple(plan) if stride1 else "patch_gemm_kernel(strided classes)"
+    PROFILE.records.append((key, flops, e0, e1))
+
+
 def pad32(n: int) -> int:
     return (n + 31) // 32 * 32
 
@@ -86,7 +132,9 @@ def conv_fwd(spec: ConvSpec, x, wp_f, bias=None, residual=None, act=ACT_NONE, ou
         raise RuntimeError("conv_fwd: bias size mismatch")
     _chk(x, wp_f, bias, residual, y)
     d = spec.desc(b, t, h, w)
+    e0 = _prof_begin()
     _hip.check(lib.p2i_conv_fwd(d, _ptr(x), _ptr(wp_f), _ptr(bias), _ptr(residual), _ptr(y), act, _stream()), "p2i_conv_fwd")
+    _prof_end(e0, "fwd", spec, d, True)
     return y
 
 
@@ -109,7 +157,9 @@ def conv_dgrad(spec: ConvSpec, dy, wp_d, in_shape, y_act=None, act=ACT_NONE, add
     dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
     _chk(dy, wp_d, y_act, dx, add)
     d = spec.desc(b, t, h, w)
+    e0 = _prof_begin()
     _hip.check(lib.p2i_conv_dgrad(d, _ptr(dy), _ptr(y_act), act, _ptr(wp_d), _ptr(add), _ptr(dx), _stream()), "p2i_conv_dgrad")
+    _prof_end(e0, "dgrad", spec, d, spec.stride == (1, 1, 1))
     return dx
 
 
@@ -127,7 +177,9 @@ def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False)
     db = torch.zeros(spec.cout, device=x.device, dtype=torch.float32) if want_bias else None
     _chk(x, dy, y_act, dwp, db)
     d = spec.desc(b, t, h, w)
+    e0 = _prof_begin()
     _hip.check(lib.p2i_conv_wgrad(d, _ptr(x), _ptr(dy), _ptr(y_act), act, _ptr(dwp), _ptr(db), _stream()), "p2i_conv_wgrad")
+    _prof_end(e0, "wgrad", spec, d, True)
     return dwp, db
 
 
