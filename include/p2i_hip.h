@@ -44,7 +44,10 @@ const char* p2i_last_error(void);
  *
  * p2i_conv_fwd :  y = act(conv(x, W) + bias) + residual
  * p2i_conv_dgrad: dx = conv_transpose(dy * act'(y), W) + dx_add   (Wd = pack with roles swapped;
- *                 dx_add, dx-shaped or NULL, fuses the skip-path gradient of a residual block)
+ *                 dx_add, dx-shaped or NULL, fuses the skip-path gradient of a residual block;
+ *                 mask_y (dx-shaped or NULL): dx is finally multiplied by mask_act'(mask_y), the
+ *                 derivative of the activation that produced this layer's INPUT, so the next
+ *                 dgrad/wgrad up the chain consume a ready gradient and need no prologue)
  * p2i_conv_wgrad: dWp[tap][cin][cout_pad] += sum_pixels x * (dy * act'(y))   (atomic fp32 adds;
  *                 caller zeroes dWp), db[cout] += sum dy*act'(y) when db != NULL.
  * dims: x (B,Cin,Ti,Hi,Wi), y (B,Cout,To,Ho,Wo); kernel (kt,kh,kw); stride (st,sh,sw);
@@ -62,7 +65,8 @@ typedef struct {
 int p2i_conv_fwd(const p2i_conv_desc* d, const float* x, const float* wp, const float* bias,
                  const float* residual, float* y, int act, void* stream);
 int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const float* y_act, int act,
-                   const float* wp_d, const float* dx_add, float* dx, void* stream);
+                   const float* wp_d, const float* dx_add, const float* mask_y, int mask_act,
+                   float* dx, void* stream);
 int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, const float* y_act,
                    int act, float* dwp, float* dbias, void* stream);
 /* tile plan {MB, NPIX, WAVES_M, CK} of the calling thread's most recent fwd/dgrad launch (names the

@@ -49,6 +49,13 @@ struct PatchGeom {
   unsigned mg_rpc, mg_eth, mg_eh;
   short tap_w[MAX_TAPS];
   int tap_off[MAX_TAPS];
+  // ---- DMA-pipelined variant only
+  const float* mask_y;  // epilogue: dst *= act'(mask_y) (dest-shaped; the activation that PRODUCED dst's tensor)
+  int mask_act;
+  int CSl;              // linear (unpadded) patch channel stride = rpc * eW
+  int PT;               // patch dwords per chunk = CK * CSl
+  unsigned src_bytes, wp_bytes;
+  unsigned mg_csl, mg_ew;
 };
 
 template <int MB, int NPIX, int WAVES_M, int CK>
@@ -181,6 +188,178 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(const PatchGeom g) {
           v = act_apply(v, g.act_epi);
           const size_t di = ((size_t)(gb * g.Cm + o)) * g.dT * dHW + sp;
           if (g.res) v += g.res[di];
+          if (g.mask_y) v = act_grad(v, g.mask_y[di], g.mask_act);
+          g.dst[di] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ DMA-pipelined patch GEMM
+// Same tiling and MFMA loop as patch_gemm_kernel, but the K-chunks are double-buffered in LDS and
+// filled by LDS-DMA (`buffer_load_dword{,x4} ... lds`): no staging VGPRs, no ds_write, and chunk k+1 is
+// in flight while chunk k is multiplied (one barrier per chunk).  Border / channel-tail zero fill
+// comes from the buffer descriptor's range check (invalid lanes carry an out-of-range voffset).
+// The per-element source offsets are computed ONCE per workgroup into an LDS table; the chunk's
+// channel base goes in the instruction's scalar offset.  LDS images are lane-linear (DMA writes
+// wave-base + lane*size), hence the unpadded patch pitch eW and channel stride CSl.
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int MB, int NPIX, int WAVES_M, int CK>
+__global__ __launch_bounds__(256) void patch_gemm_dma_kernel(const PatchGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int TM = MB / (32 * WAVES_M);
+  constexpr int TN = NPIX / (32 * WAVES_N);
+  constexpr int V = MB / 4;                          // float4 per weight row
+  const int nwrows = g.ntaps * CK;
+  const int WSZ = ((nwrows * V + 63) & ~63) * 4;     // weight floats per chunk (padded to whole wave-instructions)
+  const int PTp = (g.PT + 63) & ~63;                 // patch dwords per chunk, padded to a wave-instruction
+  int* wtab = reinterpret_cast<int*>(smem);          // [nwrows] (padded to 64)
+  const int wtab_sz = (nwrows + 63) & ~63;
+  int* ptab = wtab + wtab_sz;                        // [PTp]
+  float* buf0 = smem + wtab_sz + PTp;                // [2][WSZ + PTp]
+  const int BUFSZ = WSZ + PTp;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  int tile = blockIdx.x;
+  const int tw = tile % g.ntw; tile /= g.ntw;
+  const int th = tile % g.nth; tile /= g.nth;
+  const int tt = tile % g.ntt;
+  const int tb = tile / g.ntt;
+  const int j0b = tb << g.ljb, j0t = tt << g.ljt, j0h = th << g.ljh, j0w = tw << g.ljw;
+  const int o0 = blockIdx.y * MB;
+  const int JWm = (1 << g.ljw) - 1, JHm = (1 << g.ljh) - 1, JTm = (1 << g.ljt) - 1;
+  const int sHW = g.sH * g.sW;
+  const int src_t0 = j0t * g.mT + g.bT, src_h0 = j0h * g.mH + g.bH, src_w0 = j0w * g.mW + g.bW;
+
+  // ---- offset tables (bytes; 0xFFFFFFFC = out of range -> DMA writes 0)
+  for (int r = tid; r < wtab_sz; r += 256) {
+    int off = -4;
+    if (r < nwrows) {
+      const int tap = r / CK, c = r - tap * CK;
+      if (c < g.Ck && o0 < g.CmPad) off = ((g.tap_w[tap] * g.Ck + c) * g.CmPad + o0) * 4;
+    }
+    wtab[r] = off;
+  }
+  for (int e = tid; e < PTp; e += 256) {
+    int off = -4;
+    if (e < g.PT) {
+      const int c = fast_div(e, g.mg_csl);
+      int rem = e - c * g.CSl;
+      const int row = fast_div(rem, g.mg_ew);
+      const int ew = rem - row * g.eW;
+      const int jb = fast_div(row, g.mg_eth);
+      int r2 = row - jb * g.eth;
+      const int et = fast_div(r2, g.mg_eh);
+      const int eh = r2 - et * g.eH;
+      const int b = j0b + jb, t = src_t0 + et, h = src_h0 + eh, w = src_w0 + ew;
+      if (b < g.B && c < g.Ck && (unsigned)t < (unsigned)g.sT && (unsigned)h < (unsigned)g.sH && (unsigned)w < (unsigned)g.sW)
+        off = ((((b * g.Ck + c) * g.sT + t) * sHW) + h * g.sW + w) * 4;
+    }
+    ptab[e] = off;
+  }
+
+  int lane_base[TN];
+#pragma unroll
+  for (int f = 0; f < TN; ++f) {
+    const int pix = (wn * TN + f) * 32 + l31;
+    const int jw = pix & JWm;
+    const int jh = (pix >> g.ljw) & JHm;
+    const int jt = (pix >> (g.ljw + g.ljh)) & JTm;
+    const int jb = pix >> (g.ljw + g.ljh + g.ljt);
+    lane_base[f] = ((jb * g.eT + jt * g.mT) * g.eH + jh * g.mH) * g.eW + jw * g.mW + lhi * g.CSl;
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int f = 0; f < TN; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][f][r] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.src), 0, g.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.wp), 0, g.wp_bytes, 0x00020000);
+  const int chan_bytes = g.sT * sHW * 4;             // source bytes per channel
+  const int wbase = tid & ~63;                       // wave-uniform part of this thread's linear index
+  const int nwv = nwrows * V;                        // float4 per chunk
+  __syncthreads();                                   // tables visible
+
+  auto issue = [&](int c0, float* buf) {
+    const int w_soff = c0 * g.CmPad * 4;
+    for (int f0 = 0; f0 < nwv; f0 += 256) {          // weights: 16 B per lane
+      const int f = f0 + tid;
+      int voff = -4;
+      if (f < nwv) {
+        const int row = f / V, col4 = f - row * V;
+        const int base = wtab[row];
+        voff = base < 0 ? -4 : base + col4 * 16;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(buf + (f0 + wbase) * 4), 16, voff, w_soff, 0, 0);
+    }
+    float* pb = buf + WSZ;
+    const int p_soff = c0 * chan_bytes;
+    for (int e0 = 0; e0 < PTp; e0 += 256) {          // patch: 4 B per lane
+      const int e = e0 + tid;
+      const int voff = e < PTp ? ptab[e] : -4;
+      if (e0 + wbase < PTp)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(pb + e0 + wbase), 4, voff, p_soff, 0, 0);
+    }
+  };
+
+  const int nchunks = (g.Ck + CK - 1) / CK;
+  issue(0, buf0);
+  for (int k = 0; k < nchunks; ++k) {
+    __syncthreads();                                 // chunk k landed (vmcnt(0) + barrier); buffer (k+1)&1 is free
+    float* cur = buf0 + (k & 1) * BUFSZ;
+    if (k + 1 < nchunks) issue((k + 1) * CK, buf0 + ((k + 1) & 1) * BUFSZ);
+    const float* lw = cur;
+    const float* lp = cur + WSZ;
+    for (int tap = 0; tap < g.ntaps; ++tap) {
+      const int toff = g.tap_off[tap];
+      const float* wt = lw + tap * CK * MB + lhi * MB + wm * TM * 32 + l31;
+#pragma unroll
+      for (int cp = 0; cp < CK / 2; ++cp) {
+        float a[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = wt[cp * 2 * MB + i * 32];
+#pragma unroll
+        for (int f = 0; f < TN; ++f) bv[f] = lp[lane_base[f] + toff + cp * 2 * g.CSl];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int f = 0; f < TN; ++f)
+            acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[f], acc[i][f], 0, 0, 0);
+      }
+    }
+  }
+
+  const int dHW = g.dH * g.dW;
+#pragma unroll
+  for (int f = 0; f < TN; ++f) {
+    const int pix = (wn * TN + f) * 32 + l31;
+    const int gw = j0w + (pix & JWm);
+    const int gh = j0h + ((pix >> g.ljw) & JHm);
+    const int gt = j0t + ((pix >> (g.ljw + g.ljh)) & JTm);
+    const int gb = j0b + (pix >> (g.ljw + g.ljh + g.ljt));
+    const bool pv = gb < g.B && gt < g.nT && gh < g.nH && gw < g.nW;
+    const int sp = (gt * g.oT + g.pT) * dHW + (gh * g.oH + g.pH) * g.dW + gw * g.oW + g.pW;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (pv && o < g.Cm) {
+          float v = acc[i][f][r];
+          if (g.bias) v += g.bias[o];
+          v = act_apply(v, g.act_epi);
+          const size_t di = ((size_t)(gb * g.Cm + o)) * g.dT * dHW + sp;
+          if (g.res) v += g.res[di];
+          if (g.mask_y) v = act_grad(v, g.mask_y[di], g.mask_act);
           g.dst[di] = v;
         }
       }
@@ -211,6 +390,10 @@ struct WgradGeom {
   unsigned mg_rpc, mg_eth, mg_eh;
   int tap_off[MAX_TAPS];
   int tap_dt[MAX_TAPS];  // tap's t delta relative to bT (patch staged per group with eT rows)
+  // ---- DMA-pipelined variant
+  int eWq, XSZ, YSZ;     // odd x-row pitch; x / dy dwords per stage
+  int tap_offq[9];       // tap offsets in the [row][c][eWq] image
+  unsigned mg_ewq, mg_pp, x_bytes, dy_bytes;
 };
 
 // block: 64 x-channels (M) x 64 dy-channels (N); waves 2x2; each wave one 32x32 tile per tap (<=9)
@@ -322,6 +505,116 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g) {
   }
 }
 
+// ------------------------------------------------------------------------------------ DMA-pipelined wgrad
+// dWp[tap][c][o] += sum_pixels x[c][pix + tap] * dy[o][pix].  MFMA: A = x (m = c, lanes), B = dy (n = o,
+// lanes), K = pixels (2 per v_mfma_f32_32x32x2).  Lanes index channels, so both LDS images give
+// consecutive channels an ODD stride (x: [patch row][c][eWq], dy: [o][NPIX+1]) => conflict-free
+// ds_read_b32, while staying lane-linear for LDS-DMA (each dword's source is a per-lane gather; border
+// zeros come from the buffer range check).  Pixel tiles are double-buffered: tile k+1 streams in
+// while tile k is multiplied.  Block = 64 c x 64 o, waves 2x2, <= 9 tap accumulators per wave.
+template <int NPIX, int NTAP>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int XSZp = g.XSZ, YSZp = (g.YSZ + 63) & ~63;       // XSZ = rows * 64 * eWq is a multiple of 64
+  const int BUFSZ = XSZp + YSZp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int c0 = blockIdx.y * 64, o0 = blockIdx.z * 64;
+  const int JW = 1 << g.ljw;
+  const int JWm = JW - 1, JHm = (1 << g.ljh) - 1;
+  const int sHW = g.sH * g.sW, nHW = g.nH * g.nW;
+  const int nrow_pix = NPIX >> g.ljw;
+  const int wbase = tid & ~63;
+  const int rowblk = 64 * g.eWq;                            // dwords per patch row (all 64 channels)
+  const int nprow = g.XSZ / rowblk;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, g.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dy), 0, g.dy_bytes, 0x00020000);
+
+  f32x16 acc[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto issue = [&](int tile, float* buf) {
+    int tl = tile;
+    const int tw = tl % g.ntw; tl /= g.ntw;
+    const int th = tl % g.nth; tl /= g.nth;
+    const int tt = tl % g.ntt;
+    const int tb = tl / g.ntt;
+    const int j0b = tb << g.ljb, j0h = th << g.ljh, j0w = tw << g.ljw;
+    const int st = tt * g.mT + g.bT, sh0 = j0h * g.mH + g.bH, sw0 = j0w * g.mW + g.bW;
+    const bool tvalid = (unsigned)st < (unsigned)g.sT;
+    for (int prow = 0; prow < nprow; ++prow) {          // x image [prow][c][eWq]; prow-level math is scalar
+      const int jb = prow / g.eH, eh = prow - jb * g.eH;
+      const int b = j0b + jb, h = sh0 + eh;
+      const bool rok = tvalid && b < g.B && (unsigned)h < (unsigned)g.sH;
+      const int rbase = ((b * g.Cx + c0) * g.sT + st) * sHW + h * g.sW + sw0;
+      float* rb = buf + prow * rowblk;
+      for (int e0 = 0; e0 < rowblk; e0 += 256) {
+        const int e = e0 + tid;
+        const int c = fast_div(e, g.mg_ewq);
+        const int xx = e - c * g.eWq;
+        const bool ok = rok && e < rowblk && c0 + c < g.Cx && (unsigned)(sw0 + xx) < (unsigned)g.sW;
+        const int voff = ok ? (rbase + c * g.sT * sHW + xx) * 4 : -4;
+        if (e0 + wbase < rowblk) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(rb + e0 + wbase), 4, voff, 0, 0, 0);
+      }
+    }
+    float* yb = buf + XSZp;
+    for (int e0 = 0; e0 < YSZp; e0 += 256) {            // dy image [o][NPIX + 1]
+      const int e = e0 + tid;
+      const int o = fast_div(e, g.mg_pp);
+      const int pp = e - o * (NPIX + 1);
+      const int jw = pp & JWm, r = pp >> g.ljw;
+      const int jh = r & JHm, jb = r >> g.ljh;
+      const int b = j0b + jb, h = j0h + jh, w = j0w + jw, oc = o0 + o;
+      const bool ok = e < g.YSZ && pp < NPIX && b < g.B && oc < g.Co && h < g.nH && w < g.nW;
+      const int voff = ok ? ((((b * g.Co + oc) * g.nT + tt) * nHW) + h * g.nW + w) * 4 : -4;
+      if (e0 + wbase < YSZp) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void*)(yb + e0 + wbase), 4, voff, 0, 0, 0);
+    }
+  };
+
+  int toff[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) toff[t] = g.tap_offq[t];
+  const int xlane = (wm * 32 + l31) * g.eWq + lhi * g.mW;
+  const int ylane = (wn * 32 + l31) * (NPIX + 1) + lhi;
+  int k = 0;
+  if ((int)blockIdx.x < g.ntiles) issue(blockIdx.x, smem);
+  for (int tile = blockIdx.x; tile < g.ntiles; tile += g.nsplit, ++k) {
+    __syncthreads();
+    float* cur = smem + (k & 1) * BUFSZ;
+    if (tile + g.nsplit < g.ntiles) issue(tile + g.nsplit, smem + ((k + 1) & 1) * BUFSZ);
+    const float* xa = cur + xlane;
+    const float* yb = cur + XSZp + ylane;
+    for (int pr = 0; pr < nrow_pix; ++pr) {
+      const int jh = pr & JHm, jb = pr >> g.ljh;
+      const float* xr = xa + (jb * g.eH + jh * g.mH) * rowblk;
+      const float* yr = yb + pr * JW;
+#pragma unroll 2
+      for (int s2 = 0; s2 < JW; s2 += 2) {
+        const float bv = yr[s2];
+        const float* xp = xr + s2 * g.mW;
+        float av[NTAP];
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) av[t] = xp[toff[t]];
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    const int o = o0 + wn * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (c < g.Cx && o < g.Co) atomicAdd(g.dwp + ((size_t)(t * g.Cx + c)) * g.CoPad + o, acc[t][r]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ host side
 struct TileCfg { int MB, NPIX, WM, CK; };
 
@@ -347,6 +640,37 @@ static int launch_patch(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s
   }
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, g);
   return launch_status();
+}
+
+template <int MB, int NPIX, int WM, int CK>
+static int launch_patch_dma(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
+  auto k = patch_gemm_dma_kernel<MB, NPIX, WM, CK>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, g);
+  return launch_status();
+}
+
+static int dispatch_patch_dma(const TileCfg& c, const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
+#define P2I_CASE(mb_, npix_, wm_, ck_) \
+  if (c.MB == mb_ && c.NPIX == npix_ && c.WM == wm_ && c.CK == ck_) return launch_patch_dma<mb_, npix_, wm_, ck_>(g, grid, lds, s);
+  P2I_CASE(128, 256, 2, 8)
+  P2I_CASE(64, 256, 1, 8)
+  P2I_CASE(128, 128, 2, 8)
+  P2I_CASE(64, 128, 2, 8)
+  P2I_CASE(32, 128, 1, 8)
+  P2I_CASE(128, 256, 2, 4)
+  P2I_CASE(64, 256, 1, 4)
+  P2I_CASE(64, 128, 2, 4)
+  P2I_CASE(32, 128, 1, 4)
+  P2I_CASE(64, 128, 2, 2)
+  P2I_CASE(32, 128, 1, 2)
+#undef P2I_CASE
+  set_error("no DMA kernel instance for tile cfg %d %d %d %d", c.MB, c.NPIX, c.WM, c.CK);
+  return P2I_EINVAL;
 }
 
 static int dispatch_patch(const TileCfg& c, const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
@@ -396,6 +720,69 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
     }
   }
   g.bT = lo[0]; g.bH = lo[1]; g.bW = lo[2];
+
+  // ---- DMA-pipelined path (no act'(y) prologue): pick the largest tile that still fills the chip
+  if (g.src_y == nullptr) {
+    static const int cand[5][3] = {{128, 256, 2}, {64, 256, 1}, {128, 128, 2}, {64, 128, 2}, {32, 128, 1}};
+    const long long total_pix = (long long)g.B * cs.nT * cs.nH * cs.nW;
+    int best = -1, best_ck = 0;
+    long long best_score = -1;
+    PatchGeom bg = g;
+    size_t best_lds = 0;
+    dim3 best_grid;
+    for (int ci = 0; ci < 5; ++ci) {
+      const int MBc = cand[ci][0], NP = cand[ci][1];
+      if (MBc > 32 && g.Cm <= MBc / 2) continue;            // more than half of the m-tile would be padding
+      int jb, jt, jh, jw;
+      pick_tile_dims(NP, g.B, cs.nT, cs.nH, cs.nW, jb, jt, jh, jw);
+      PatchGeom t = g;
+      t.ljb = ilog2(jb); t.ljt = ilog2(jt); t.ljh = ilog2(jh); t.ljw = ilog2(jw);
+      t.eT = (jt - 1) * cs.mT + (hi[0] - lo[0]) + 1;
+      t.eH = (jh - 1) * cs.mH + (hi[1] - lo[1]) + 1;
+      t.eW = (jw - 1) * cs.mW + (hi[2] - lo[2]) + 1;
+      t.eWp = t.eW;
+      t.eth = t.eT * t.eH;
+      t.rpc = jb * t.eth;
+      t.CSl = t.rpc * t.eW;
+      t.CS = t.CSl;
+      for (int CKc = 8; CKc >= 2; CKc >>= 1) {
+        if (g.Ck >= CKc ? (g.Ck % CKc != 0) : (CKc != 2 && g.Ck * 2 <= CKc)) continue;
+        if (CKc == 2 && !(MBc == 64 && NP == 128) && !(MBc == 32)) continue;      // instantiated CK=2 tiles
+        if (CKc == 4 && MBc == 128 && NP == 128) continue;
+        const int PT = CKc * t.CSl;
+        if (PT >= 65536 || t.CSl >= 65536) continue;
+        const int PTp = (PT + 63) & ~63;
+        const int nwrows = cs.ntaps * CKc;
+        const size_t WSZ = (size_t)((nwrows * (MBc / 4) + 63) & ~63) * 4;
+        const size_t lds = sizeof(float) * (((nwrows + 63) & ~63) + (size_t)PTp + 2 * (WSZ + PTp));
+        if (lds > 160 * 1024) continue;
+        const long long nb = (long long)ceil_div(g.Cm, MBc) * ((total_pix + NP - 1) / NP);
+        // score: filling the chip first, then MFMA work per staged byte (tile area), then deeper chunks
+        long long score = (nb >= 256 ? 1000000000ll : nb * 1000000ll) + (long long)MBc * NP * 10 + CKc + (lds <= 80 * 1024 ? 5 : 0);
+        if (score > best_score) {
+          best_score = score; best = ci; best_ck = CKc; best_lds = lds;
+          bg = t; bg.PT = PT;
+          bg.ntt = ceil_div(cs.nT, jt); bg.nth = ceil_div(cs.nH, jh); bg.ntw = ceil_div(cs.nW, jw);
+          best_grid = dim3((unsigned)(ceil_div(g.B, jb) * bg.ntt * bg.nth * bg.ntw), (unsigned)ceil_div(g.Cm, MBc));
+        }
+        break;   // largest feasible CK for this tile
+      }
+    }
+    const unsigned long long sbytes = 4ull * g.B * g.Ck * g.sT * g.sH * g.sW;
+    if (best >= 0 && sbytes < 0xF0000000ull) {
+      TileCfg c{cand[best][0], cand[best][1], cand[best][2], best_ck};
+      bg.mg_csl = magic_u16(bg.CSl); bg.mg_ew = magic_u16(bg.eW);
+      bg.mg_rpc = magic_u16(bg.rpc); bg.mg_eth = magic_u16(bg.eth); bg.mg_eh = magic_u16(bg.eH);
+      bg.src_bytes = (unsigned)sbytes;
+      bg.wp_bytes = g.wp_bytes;
+      for (int i = 0; i < cs.ntaps; ++i) {
+        bg.tap_w[i] = cs.tw[i];
+        bg.tap_off[i] = ((cs.dt[i] - lo[0]) * bg.eH + (cs.dh[i] - lo[1])) * bg.eW + (cs.dw[i] - lo[2]);
+      }
+      g_last_plan[0] = c.MB; g_last_plan[1] = c.NPIX; g_last_plan[2] = c.WM; g_last_plan[3] = c.CK;
+      return dispatch_patch_dma(c, bg, best_grid, best_lds, s);
+    }
+  }
 
   // ---- tile configuration
   TileCfg c;
@@ -480,6 +867,7 @@ extern "C" int p2i_conv_fwd(const p2i_conv_desc* d, const float* x, const float*
   PatchGeom g{};
   g.src = x; g.src_y = nullptr; g.wp = wp; g.bias = bias; g.res = residual; g.dst = y; g.act_epi = act; g.act_pro = P2I_ACT_NONE;
   g.B = d->B; g.Ck = d->Cin; g.Cm = d->Cout; g.CmPad = (d->Cout + 31) / 32 * 32;
+  g.wp_bytes = 4u * (unsigned)(d->kt * d->kh * d->kw) * g.Ck * g.CmPad;
   g.sT = d->Ti; g.sH = d->Hi; g.sW = d->Wi; g.dT = d->To; g.dH = d->Ho; g.dW = d->Wo;
   ClassSpec cs{};
   cs.nT = d->To; cs.nH = d->Ho; cs.nW = d->Wo;
@@ -496,12 +884,16 @@ extern "C" int p2i_conv_fwd(const p2i_conv_desc* d, const float* x, const float*
 }
 
 extern "C" int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const float* y_act, int act,
-                              const float* wp_d, const float* dx_add, float* dx, void* stream) {
+                              const float* wp_d, const float* dx_add, const float* mask_y, int mask_act,
+                              float* dx, void* stream) {
   if (int e = check_desc(d)) return e;
   P2I_REQUIRE(dy && wp_d && dx, "null pointer");
   PatchGeom g{};
   g.src = dy; g.src_y = y_act; g.wp = wp_d; g.bias = nullptr; g.res = dx_add; g.dst = dx; g.act_epi = P2I_ACT_NONE; g.act_pro = y_act ? act : P2I_ACT_NONE;
+  g.mask_y = mask_y; g.mask_act = mask_y ? mask_act : P2I_ACT_NONE;
+  P2I_REQUIRE(!(mask_y && y_act), "dgrad: use either the act'(y) prologue or the epilogue mask");
   g.B = d->B; g.Ck = d->Cout; g.Cm = d->Cin; g.CmPad = (d->Cin + 31) / 32 * 32;
+  g.wp_bytes = 4u * (unsigned)(d->kt * d->kh * d->kw) * g.Ck * g.CmPad;
   g.sT = d->To; g.sH = d->Ho; g.sW = d->Wo; g.dT = d->Ti; g.dH = d->Hi; g.dW = d->Wi;
   // one launch per parity class of the input index modulo the stride
   for (int ct = 0; ct < d->st; ++ct)
@@ -583,8 +975,43 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<NPIX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  // one launch per kt slice (the patch's t origin differs per slice)
-  for (int a = 0; a < d->kt; ++a) {
+  // ---- DMA-pipelined variant (no act'(y) prologue): [row][c][eWq] / [o][NPIX+1] images, double buffered
+  bool use_dma = (y_act == nullptr);
+  if (use_dma) {
+    g.eWq = g.eW | 1;
+    g.XSZ = jb * g.eH * 64 * g.eWq;
+    g.YSZ = 64 * (NPIX + 1);
+    const size_t lds2 = sizeof(float) * 2 * ((size_t)((g.XSZ + 63) & ~63) + ((g.YSZ + 63) & ~63));
+    const unsigned long long xb = 4ull * d->B * d->Cin * d->Ti * d->Hi * d->Wi, yb = 4ull * d->B * d->Cout * d->To * d->Ho * d->Wo;
+    if ((g.tpg != 9 && g.tpg != 1) || lds2 > 160 * 1024 || g.XSZ >= 65536 || xb >= 0xF0000000ull || yb >= 0xF0000000ull) use_dma = false;
+    else {
+      g.mg_ewq = magic_u16(g.eWq); g.mg_pp = magic_u16(NPIX + 1);
+      g.x_bytes = (unsigned)xb; g.dy_bytes = (unsigned)yb;
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<NPIX, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<NPIX, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr2 = true;
+      }
+      int ns = 256 / (ncx * nco);        // LDS admits one block per CU: one resident block per CU, few atomics
+      if (ns < 1) ns = 1;
+      if (ns > g.ntiles) ns = g.ntiles;
+      for (int a = 0; a < d->kt; ++a) {
+        WgradGeom ga = g;
+        ga.bT = a - d->pt;
+        ga.ntaps = g.tpg;
+        ga.nsplit = ns;
+        ga.dwp = dwp + (size_t)a * g.tpg * d->Cin * g.CoPad;
+        for (int b = 0; b < d->kh; ++b)
+          for (int c = 0; c < d->kw; ++c) ga.tap_offq[b * d->kw + c] = b * 64 * g.eWq + c;
+        if (g.tpg == 9) hipLaunchKernelGGL((wgrad_dma_kernel<NPIX, 9>), dim3(ns, ncx, nco), dim3(256), lds2, s, ga);
+        else hipLaunchKernelGGL((wgrad_dma_kernel<NPIX, 1>), dim3(ns, ncx, nco), dim3(256), lds2, s, ga);
+        if (int e = launch_status()) return e;
+      }
+    }
+  }
+  if (!use_dma)
+  for (int a = 0; a < d->kt; ++a) {   // one launch per kt slice (the patch's t origin differs per slice)
     WgradGeom ga = g;
     ga.bT = a - d->pt;
     ga.ntaps = g.tpg;

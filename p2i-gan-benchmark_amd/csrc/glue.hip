@@ -292,22 +292,24 @@ __global__ void dtail_bwd3_kernel(const float* __restrict__ df, float* do3, int 
 }
 
 // ------------------------------------------------------------------ misc
-// db[c] += sum_{b, inner} dy * act'(y); one block per channel
+// db[c] += sum_{b, inner} dy * act'(y); grid (C, chunks): block partial sums combined by one atomic each
 __global__ void bias_grad_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, float* db, int B, int C,
                                  int64_t inner) {
   __shared__ float red[16];
   const int c = blockIdx.x;
+  const int64_t total = (int64_t)B * inner;
+  const int64_t per = (total + gridDim.y - 1) / gridDim.y;
+  const int64_t lo = per * blockIdx.y, hi = lo + per < total ? lo + per : total;
   float acc = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const size_t base = ((size_t)b * C + c) * inner;
-    for (int64_t i = threadIdx.x; i < inner; i += blockDim.x) {
-      float g = dy[base + i];
-      if (y) g = act_grad(g, y[base + i], act);
-      acc += g;
-    }
+  for (int64_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+    const int64_t b = j / inner, i = j - b * inner;
+    const size_t idx = ((size_t)b * C + c) * inner + i;
+    float g = dy[idx];
+    if (y) g = act_grad(g, y[idx], act);
+    acc += g;
   }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) db[c] += acc;
+  if (threadIdx.x == 0) atomicAdd(db + c, acc);
 }
 __global__ void axpy_kernel(float* y, const float* __restrict__ x, float a, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += a * x[i];
@@ -404,7 +406,11 @@ extern "C" int p2i_dtail_bwd(const float* out2d, const float* alpha2d, const flo
 }
 extern "C" int p2i_bias_grad(const float* dy, const float* y_act, int act, float* db, int B, int C, int64_t inner, void* stream) {
   P2I_REQUIRE(dy && db, "null pointer");
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, y_act, act, db, B, C, inner);
+  const int64_t total = (int64_t)B * inner;
+  int chunks = (int)((total + 16383) / 16384);
+  if (chunks > 64) chunks = 64;
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dy, y_act, act, db, B, C, inner);
   return launch_status();
 }
 extern "C" int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stream) {

@@ -74,19 +74,36 @@ __global__ void fold_bwd_w_kernel(const float* __restrict__ dwp, const float* __
   }
 }
 
-// dD[i][m][s] = sum_{o'} dDoW[o',i,m] * W[o',i,s]; block per i, thread per (m,s)
-__global__ void fold_bwd_d_kernel(const float* __restrict__ dwp, const float* __restrict__ W, int O, int I, int groups,
-                                  float* dD) {
-  const int i = blockIdx.x, ms = threadIdx.x;
-  if (ms >= 81) return;
-  const int m = ms / 9, s = ms - m * 9;
+// dD[i][m][s] = sum_{o'} dDoW[o',i,m] * W[o',i,s]; block per i, threads stride over o' (coalesced dDoW reads),
+// 81 register accumulators per thread, wave shuffle + LDS combine
+__global__ __launch_bounds__(256) void fold_bwd_d_kernel(const float* __restrict__ dwp, const float* __restrict__ W, int O, int I,
+                                                        int groups, float* dD) {
+  __shared__ float part[4][81];
+  const int i = blockIdx.x;
   const int Ig = I / groups, Og = O / groups, Opad = pad32(O);
-  float acc = 0.f;
-  for (int op = 0; op < Og; ++op) {
+  float acc[81];
+#pragma unroll
+  for (int k = 0; k < 81; ++k) acc[k] = 0.f;
+  for (int op = threadIdx.x; op < Og; op += blockDim.x) {
     const int q = op * I + i, o = q / Ig, ci = q - o * Ig, cin = (o / Og) * Ig + ci;
-    acc += dwp[((size_t)m * I + cin) * Opad + o] * W[(size_t)q * 9 + s];
+    float gm[9], ws[9];
+#pragma unroll
+    for (int m = 0; m < 9; ++m) gm[m] = dwp[((size_t)m * I + cin) * Opad + o];
+#pragma unroll
+    for (int s2 = 0; s2 < 9; ++s2) ws[s2] = W[(size_t)q * 9 + s2];
+#pragma unroll
+    for (int m = 0; m < 9; ++m)
+#pragma unroll
+      for (int s2 = 0; s2 < 9; ++s2) acc[m * 9 + s2] += gm[m] * ws[s2];
   }
-  dD[(i * 9 + m) * 9 + s] = acc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 81; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0) part[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 81) dD[i * 81 + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
 // ---- plain (O, I, NT) <-> packed
@@ -194,7 +211,7 @@ extern "C" int p2i_doconv_fold_bwd(const float* dwp_f, const float* W, const flo
   hipStream_t s = (hipStream_t)stream;
   const int n = (ksz == 1) ? O * (I / groups) : (O / groups) * I;
   hipLaunchKernelGGL(fold_bwd_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dwp_f, D, D_diag, O, I, groups, ksz, dW);
-  if (ksz == 3) hipLaunchKernelGGL(fold_bwd_d_kernel, dim3(I), dim3(128), 0, s, dwp_f, W, O, I, groups, dD);
+  if (ksz == 3) hipLaunchKernelGGL(fold_bwd_d_kernel, dim3(I), dim3(256), 0, s, dwp_f, W, O, I, groups, dD);
   return launch_status();
 }
 

@@ -217,10 +217,10 @@ class _GeneratorFn(torch.autograd.Function):
                 c1, c2 = _doconv_of(rb.main[0]), _doconv_of(rb.main[1])
                 dwp2, _ = ops.conv_wgrad(spec, y1, dh)
                 grads[id(c2.W)], grads[id(c2.D)] = ops.doconv_fold_bwd(dwp2, *c2.tensors(), ch, ch, 1, 3)
-                dy1 = ops.conv_dgrad(spec, dh, w2d, tuple(y1.shape))
-                dwp1, _ = ops.conv_wgrad(spec, hin, dy1, y1, ACT_RELU)
+                dy1 = ops.conv_dgrad(spec, dh, w2d, tuple(y1.shape), mask_y=y1, mask_act=ACT_RELU)   # * relu'(y1) fused
+                dwp1, _ = ops.conv_wgrad(spec, hin, dy1)
                 grads[id(c1.W)], grads[id(c1.D)] = ops.doconv_fold_bwd(dwp1, *c1.tensors(), ch, ch, 1, 3)
-                dh = ops.conv_dgrad(spec, dy1, w1d, tuple(hin.shape), y1, ACT_RELU, add=dh)   # + skip path
+                dh = ops.conv_dgrad(spec, dy1, w1d, tuple(hin.shape), add=dh)                     # + skip path
             return dh
 
         def uppos_bwd(i, dr):
@@ -373,18 +373,19 @@ class _DiscriminatorFn(torch.autograd.Function):
         gw, gb = {}, {}
 
         def branch_bwd(layers, specs, recs, dy, base, first_add=None):
+            # dy arrives already multiplied by act'(y_n): the dgrad of layer n+1 applies it in its epilogue
+            # (mask_y = that layer's input = y_n), so no kernel here needs an activation prologue
             for n in reversed(range(len(layers))):
                 m, spec, rc = layers[n], specs[n], recs[n]
-                y_act = rc["y"] if rc["act"] != ACT_NONE else None
                 if needs[2 * (base + n)] or needs[2 * (base + n) + 1]:
-                    dwp, db = ops.conv_wgrad(spec, rc["x"], dy, y_act, rc["act"], want_bias=True)
+                    dwp, db = ops.conv_wgrad(spec, rc["x"], dy, want_bias=True)
                     wo = m.weight_orig
                     wflat = wo.reshape(wo.shape[0], wo.shape[1], -1)
                     gw[base + n] = ops.weight_unpack_grad(dwp, wflat, wflat, rc["sigma"], rc["u"], rc["v"]).reshape(wo.shape)
                     gb[base + n] = db
                 if n > 0 or need_x:
-                    dy = ops.conv_dgrad(spec, dy, rc["wp_d"], tuple(rc["x"].shape), y_act, rc["act"],
-                                        add=first_add if n == 0 else None)
+                    dy = ops.conv_dgrad(spec, dy, rc["wp_d"], tuple(rc["x"].shape), add=first_add if n == 0 else None,
+                                        mask_y=rc["x"] if n > 0 else None, mask_act=ACT_LEAKY)
                 else:
                     dy = None
             return dy

@@ -138,7 +138,7 @@ def conv_fwd(spec: ConvSpec, x, wp_f, bias=None, residual=None, act=ACT_NONE, ou
     return y
 
 
-def conv_dgrad(spec: ConvSpec, dy, wp_d, in_shape, y_act=None, act=ACT_NONE, add=None):
+def conv_dgrad(spec: ConvSpec, dy, wp_d, in_shape, y_act=None, act=ACT_NONE, add=None, mask_y=None, mask_act=ACT_NONE):
     """dx for input of shape in_shape; if y_act is given dy is first multiplied by act'(y_act)."""
     lib = _hip.load()
     if len(in_shape) == 4:
@@ -154,11 +154,14 @@ def conv_dgrad(spec: ConvSpec, dy, wp_d, in_shape, y_act=None, act=ACT_NONE, add
         raise RuntimeError("conv_dgrad: y_act shape mismatch")
     if add is not None and tuple(add.shape) != tuple(in_shape):
         raise RuntimeError("conv_dgrad: add shape mismatch")
+    if mask_y is not None and tuple(mask_y.shape) != tuple(in_shape):
+        raise RuntimeError("conv_dgrad: mask_y shape mismatch")
     dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
-    _chk(dy, wp_d, y_act, dx, add)
+    _chk(dy, wp_d, y_act, dx, add, mask_y)
     d = spec.desc(b, t, h, w)
     e0 = _prof_begin()
-    _hip.check(lib.p2i_conv_dgrad(d, _ptr(dy), _ptr(y_act), act, _ptr(wp_d), _ptr(add), _ptr(dx), _stream()), "p2i_conv_dgrad")
+    _hip.check(lib.p2i_conv_dgrad(d, _ptr(dy), _ptr(y_act), act, _ptr(wp_d), _ptr(add), _ptr(mask_y), mask_act, _ptr(dx), _stream()),
+               "p2i_conv_dgrad")
     _prof_end(e0, "dgrad", spec, d, spec.stride == (1, 1, 1))
     return dx
 

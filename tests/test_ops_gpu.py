@@ -80,6 +80,11 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     y_act = y.detach().to(dev).contiguous() if act != "none" else None
     dx = ops.conv_dgrad(spec, gout.to(dev), wp_d, tuple(x.shape), y_act, act_code)
     assert rel_err(dx.cpu().numpy(), x.grad.numpy()) < TOL_OP
+    # fused epilogue: (dx + add) * relu'(mask)
+    addt, mk = _rand(*x.shape, seed=6), _rand(*x.shape, seed=7)
+    gin = gout * {"none": 1.0, "relu": (y > 0).float(), "leaky": torch.where(y > 0, 1.0, 0.2), "tanh": 1 - y * y}[act]
+    dx2 = ops.conv_dgrad(spec, gin.detach().to(dev).contiguous(), wp_d, tuple(x.shape), add=addt.to(dev), mask_y=mk.to(dev), mask_act=ops.ACT_RELU)
+    assert rel_err(dx2.cpu().numpy(), ((x.grad + addt) * (mk > 0)).numpy()) < TOL_OP
     dwp, db = ops.conv_wgrad(spec, xg, gout.to(dev), y_act, act_code, want_bias=has_bias)
     dw = ops.weight_unpack_grad(dwp, w.detach().to(dev))
     assert rel_err(dw.cpu().numpy(), w.grad.numpy()) < TOL_WGRAD
