@@ -512,19 +512,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g) {
 // ds_read_b32, while staying lane-linear for LDS-DMA (each dword's source is a per-lane gather; border
 // zeros come from the buffer range check).  Pixel tiles are double-buffered: tile k+1 streams in
 // while tile k is multiplied.  Block = 64 c x 64 o, waves 2x2, <= 9 tap accumulators per wave.
-template <int NPIX, int NTAP>
-__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradGeom g) {
+// 512 threads: waves = 2 (c tiles) x 2 (o tiles) x 2 (halves of the tile's pixels: intra-block split-K), i.e.
+// two waves per SIMD so that one wave's DMA issue / LDS waits hide under the other's MFMAs.
+// Y4: dy rows are 16-B aligned (nW % 4 == 0): dy image pitch NPIX+4 filled by 16-B DMA and read with
+// ds_read_b128 (conflict-free: 16-lane groups see 16 distinct residues of 4*o mod 64), one read per 2 k-steps.
+template <int NPIX, int NTAP, bool Y4>
+__global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int XSZp = g.XSZ, YSZp = (g.YSZ + 63) & ~63;       // XSZ = rows * 64 * eWq is a multiple of 64
-  const int BUFSZ = XSZp + YSZp;
+  constexpr int PP = Y4 ? NPIX + 4 : NPIX + 1;
+  constexpr int YSZp = ((64 * PP + 255) / 256) * 256;
+  const int XSZp = g.XSZ;                                   // rows * 64 * eWq: a multiple of 64
+  const int BUFSZ = ((XSZp + 3) & ~3) + YSZp;
+  const int YOFF = (XSZp + 3) & ~3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int c0 = blockIdx.y * 64, o0 = blockIdx.z * 64;
   const int JW = 1 << g.ljw;
   const int JWm = JW - 1, JHm = (1 << g.ljh) - 1;
   const int sHW = g.sH * g.sW, nHW = g.nH * g.nW;
-  const int nrow_pix = NPIX >> g.ljw;
   const int wbase = tid & ~63;
   const int rowblk = 64 * g.eWq;                            // dwords per patch row (all 64 channels)
   const int nprow = g.XSZ / rowblk;
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradGeom g) {
       const bool rok = tvalid && b < g.B && (unsigned)h < (unsigned)g.sH;
       const int rbase = ((b * g.Cx + c0) * g.sT + st) * sHW + h * g.sW + sw0;
       float* rb = buf + prow * rowblk;
-      for (int e0 = 0; e0 < rowblk; e0 += 256) {
+      for (int e0 = 0; e0 < rowblk; e0 += 512) {
         const int e = e0 + tid;
         const int c = fast_div(e, g.mg_ewq);
         const int xx = e - c * g.eWq;
@@ -561,17 +567,32 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradGeom g) {
         if (e0 + wbase < rowblk) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(rb + e0 + wbase), 4, voff, 0, 0, 0);
       }
     }
-    float* yb = buf + XSZp;
-    for (int e0 = 0; e0 < YSZp; e0 += 256) {            // dy image [o][NPIX + 1]
-      const int e = e0 + tid;
-      const int o = fast_div(e, g.mg_pp);
-      const int pp = e - o * (NPIX + 1);
-      const int jw = pp & JWm, r = pp >> g.ljw;
-      const int jh = r & JHm, jb = r >> g.ljh;
-      const int b = j0b + jb, h = j0h + jh, w = j0w + jw, oc = o0 + o;
-      const bool ok = e < g.YSZ && pp < NPIX && b < g.B && oc < g.Co && h < g.nH && w < g.nW;
-      const int voff = ok ? ((((b * g.Co + oc) * g.nT + tt) * nHW) + h * g.nW + w) * 4 : -4;
-      if (e0 + wbase < YSZp) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void*)(yb + e0 + wbase), 4, voff, 0, 0, 0);
+    float* yb = buf + YOFF;
+    if constexpr (Y4) {                                   // dy image [o][NPIX + 4], 16 B per lane
+      constexpr int NCH = 64 * PP / 4;                    // 16-B chunks
+      for (int q0 = 0; q0 < NCH; q0 += 512) {
+        const int q4 = q0 + tid;
+        const int o = q4 / (PP / 4);
+        const int pp = (q4 - o * (PP / 4)) * 4;
+        const int jw = pp & JWm, r = pp >> g.ljw;
+        const int jh = r & JHm, jb = r >> g.ljh;
+        const int b = j0b + jb, h = j0h + jh, w = j0w + jw, oc = o0 + o;
+        const bool ok = q4 < NCH && pp < NPIX && b < g.B && oc < g.Co && h < g.nH && w < g.nW;
+        const int voff = ok ? ((((b * g.Co + oc) * g.nT + tt) * nHW) + h * g.nW + w) * 4 : -4;
+        if (q0 + wbase < NCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void*)(yb + (q0 + wbase) * 4), 16, voff, 0, 0, 0);
+      }
+    } else {                                              // dy image [o][NPIX + 1], 4 B per lane
+      for (int e0 = 0; e0 < 64 * PP; e0 += 512) {
+        const int e = e0 + tid;
+        const int o = fast_div(e, g.mg_pp);
+        const int pp = e - o * PP;
+        const int jw = pp & JWm, r = pp >> g.ljw;
+        const int jh = r & JHm, jb = r >> g.ljh;
+        const int b = j0b + jb, h = j0h + jh, w = j0w + jw, oc = o0 + o;
+        const bool ok = e < 64 * PP && pp < NPIX && b < g.B && oc < g.Co && h < g.nH && w < g.nW;
+        const int voff = ok ? ((((b * g.Co + oc) * g.nT + tt) * nHW) + h * g.nW + w) * 4 : -4;
+        if (e0 + wbase < 64 * PP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void*)(yb + e0 + wbase), 4, voff, 0, 0, 0);
+      }
     }
   };
 
@@ -579,7 +600,11 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradGeom g) {
 #pragma unroll
   for (int t = 0; t < NTAP; ++t) toff[t] = g.tap_offq[t];
   const int xlane = (wm * 32 + l31) * g.eWq + lhi * g.mW;
-  const int ylane = (wn * 32 + l31) * (NPIX + 1) + lhi;
+  const int ylane = (wn * 32 + l31) * PP + (Y4 ? 0 : lhi);
+  constexpr int UPIX = Y4 ? 4 : 2;                        // pixels per loop unit
+  constexpr int NU = NPIX / UPIX / 2;                     // units per k-half
+  const int lju = g.ljw - (Y4 ? 2 : 1);                   // log2(units per pixel row)
+  const int upr_m = (1 << lju) - 1;
   int k = 0;
   if ((int)blockIdx.x < g.ntiles) issue(blockIdx.x, smem);
   for (int tile = blockIdx.x; tile < g.ntiles; tile += g.nsplit, ++k) {
@@ -587,15 +612,24 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradGeom g) {
     float* cur = smem + (k & 1) * BUFSZ;
     if (tile + g.nsplit < g.ntiles) issue(tile + g.nsplit, smem + ((k + 1) & 1) * BUFSZ);
     const float* xa = cur + xlane;
-    const float* yb = cur + XSZp + ylane;
-    for (int pr = 0; pr < nrow_pix; ++pr) {
+    const float* yb = cur + YOFF + ylane;
+    for (int uu = 0; uu < NU; ++uu) {
+      const int u = kh * NU + uu;
+      const int pr = u >> lju, s0 = (u & upr_m) * UPIX;
       const int jh = pr & JHm, jb = pr >> g.ljh;
-      const float* xr = xa + (jb * g.eH + jh * g.mH) * rowblk;
-      const float* yr = yb + pr * JW;
-#pragma unroll 2
-      for (int s2 = 0; s2 < JW; s2 += 2) {
-        const float bv = yr[s2];
-        const float* xp = xr + s2 * g.mW;
+      const float* xp = xa + (jb * g.eH + jh * g.mH) * rowblk + s0 * g.mW;
+      if constexpr (Y4) {
+        const float4 v = *reinterpret_cast<const float4*>(yb + pr * JW + s0);
+        const float b0 = lhi ? v.y : v.x, b1 = lhi ? v.w : v.z;
+        float a0[NTAP], a1[NTAP];
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) { a0[t] = xp[toff[t]]; a1[t] = xp[toff[t] + 2 * g.mW]; }
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1, acc[t], 0, 0, 0);
+      } else {
+        const float bv = yb[pr * JW + s0];
         float av[NTAP];
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) av[t] = xp[toff[t]];
@@ -975,25 +1009,25 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<NPIX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  // ---- DMA-pipelined variant (no act'(y) prologue): [row][c][eWq] / [o][NPIX+1] images, double buffered
-  bool use_dma = (y_act == nullptr);
+  // ---- DMA-pipelined variant (no act'(y) prologue): [row][c][eWq] / [o][PP] images, double buffered
+  bool use_dma = (y_act == nullptr) && (g.tpg == 9 || g.tpg == 1) && jw >= 8;
   if (use_dma) {
+    const bool y4 = (d->Wo % 4 == 0);
+    const int PPh = y4 ? NPIX + 4 : NPIX + 1;
     g.eWq = g.eW | 1;
     g.XSZ = jb * g.eH * 64 * g.eWq;
-    g.YSZ = 64 * (NPIX + 1);
-    const size_t lds2 = sizeof(float) * 2 * ((size_t)((g.XSZ + 63) & ~63) + ((g.YSZ + 63) & ~63));
+    g.YSZ = 64 * PPh;
+    const size_t lds2 = sizeof(float) * 2 * ((size_t)((g.XSZ + 3) & ~3) + (size_t)((64 * PPh + 255) / 256) * 256);
     const unsigned long long xb = 4ull * d->B * d->Cin * d->Ti * d->Hi * d->Wi, yb = 4ull * d->B * d->Cout * d->To * d->Ho * d->Wo;
-    if ((g.tpg != 9 && g.tpg != 1) || lds2 > 160 * 1024 || g.XSZ >= 65536 || xb >= 0xF0000000ull || yb >= 0xF0000000ull) use_dma = false;
+    if (lds2 > 160 * 1024 || g.XSZ >= 65536 || xb >= 0xF0000000ull || yb >= 0xF0000000ull) use_dma = false;
     else {
-      g.mg_ewq = magic_u16(g.eWq); g.mg_pp = magic_u16(NPIX + 1);
+      g.mg_ewq = magic_u16(g.eWq); g.mg_pp = magic_u16(PPh);
       g.x_bytes = (unsigned)xb; g.dy_bytes = (unsigned)yb;
-      static bool attr2 = false;
-      if (!attr2) {
-        (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<NPIX, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<NPIX, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr2 = true;
-      }
-      int ns = 256 / (ncx * nco);        // LDS admits one block per CU: one resident block per CU, few atomics
+      typedef void (*wk_t)(const WgradGeom);
+      wk_t kern = g.tpg == 9 ? (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true> : (wk_t)wgrad_dma_kernel<NPIX, 9, false>)
+                             : (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 1, true> : (wk_t)wgrad_dma_kernel<NPIX, 1, false>);
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      int ns = 256 / (ncx * nco);        // LDS admits one (8-wave) block per CU
       if (ns < 1) ns = 1;
       if (ns > g.ntiles) ns = g.ntiles;
       for (int a = 0; a < d->kt; ++a) {
@@ -1004,8 +1038,7 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
         ga.dwp = dwp + (size_t)a * g.tpg * d->Cin * g.CoPad;
         for (int b = 0; b < d->kh; ++b)
           for (int c = 0; c < d->kw; ++c) ga.tap_offq[b * d->kw + c] = b * 64 * g.eWq + c;
-        if (g.tpg == 9) hipLaunchKernelGGL((wgrad_dma_kernel<NPIX, 9>), dim3(ns, ncx, nco), dim3(256), lds2, s, ga);
-        else hipLaunchKernelGGL((wgrad_dma_kernel<NPIX, 1>), dim3(ns, ncx, nco), dim3(256), lds2, s, ga);
+        hipLaunchKernelGGL(kern, dim3(ns, ncx, nco), dim3(512), lds2, s, ga);
         if (int e = launch_status()) return e;
       }
     }
