@@ -299,7 +299,8 @@ __global__ __launch_bounds__(256) void patch_gemm_dma_kernel(const PatchGeom g) 
         const int base = wtab[row];
         voff = base < 0 ? -4 : base + col4 * 16;
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(buf + (f0 + wbase) * 4), 16, voff, w_soff, 0, 0);
+      if (f0 + wbase < ((nwv + 63) & ~63))   // whole waves past the padded weight area must not write (they would zero the patch)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(buf + (f0 + wbase) * 4), 16, voff, w_soff, 0, 0);
     }
     float* pb = buf + WSZ;
     const int p_soff = c0 * chan_bytes;
@@ -516,23 +517,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g) {
 // two waves per SIMD so that one wave's DMA issue / LDS waits hide under the other's MFMAs.
 // Y4: dy rows are 16-B aligned (nW % 4 == 0): dy image pitch NPIX+4 filled by 16-B DMA and read with
 // ds_read_b128 (conflict-free: 16-lane groups see 16 distinct residues of 4*o mod 64), one read per 2 k-steps.
-template <int NPIX, int NTAP, bool Y4>
+template <int NPIX, int NTAP, bool Y4, int CB>
 __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int PP = Y4 ? NPIX + 4 : NPIX + 1;
   constexpr int YSZp = ((64 * PP + 255) / 256) * 256;
-  const int XSZp = g.XSZ;                                   // rows * 64 * eWq: a multiple of 64
+  const int XSZp = g.XSZ;                                   // rows * CB * eWq
   const int BUFSZ = ((XSZp + 3) & ~3) + YSZp;
   const int YOFF = (XSZp + 3) & ~3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  constexpr int CT = CB / 32;                            // c tiles per block (1 or 2)
+  constexpr int KS = 4 / CT;                             // pixel-range splits (intra-block split-K)
+  const int wn = wave & 1, wm = (wave >> 1) & (CT - 1), kh = wave >> (CT == 2 ? 2 : 1);
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int c0 = blockIdx.y * 64, o0 = blockIdx.z * 64;
+  const int c0 = blockIdx.y * CB, o0 = blockIdx.z * 64;
   const int JW = 1 << g.ljw;
   const int JWm = JW - 1, JHm = (1 << g.ljh) - 1;
   const int sHW = g.sH * g.sW, nHW = g.nH * g.nW;
   const int wbase = tid & ~63;
-  const int rowblk = 64 * g.eWq;                            // dwords per patch row (all 64 channels)
+  const int rowblk = CB * g.eWq;                            // dwords per patch row (all CB channels)
   const int nprow = g.XSZ / rowblk;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, g.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dy), 0, g.dy_bytes, 0x00020000);
@@ -564,7 +567,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
         const int xx = e - c * g.eWq;
         const bool ok = rok && e < rowblk && c0 + c < g.Cx && (unsigned)(sw0 + xx) < (unsigned)g.sW;
         const int voff = ok ? (rbase + c * g.sT * sHW + xx) * 4 : -4;
-        if (e0 + wbase < rowblk) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(rb + e0 + wbase), 4, voff, 0, 0, 0);
+        if (e < rowblk)      // per-lane: with CB = 32 the last wave-instruction of a row is partial (exec-masked)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(rb + e0 + wbase), 4, voff, 0, 0, 0);
       }
     }
     float* yb = buf + YOFF;
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
   const int xlane = (wm * 32 + l31) * g.eWq + lhi * g.mW;
   const int ylane = (wn * 32 + l31) * PP + (Y4 ? 0 : lhi);
   constexpr int UPIX = Y4 ? 4 : 2;                        // pixels per loop unit
-  constexpr int NU = NPIX / UPIX / 2;                     // units per k-half
+  constexpr int NU = NPIX / UPIX / KS;                    // units per k-split
   const int lju = g.ljw - (Y4 ? 2 : 1);                   // log2(units per pixel row)
   const int upr_m = (1 << lju) - 1;
   int k = 0;
@@ -1009,25 +1013,36 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<NPIX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  // ---- DMA-pipelined variant (no act'(y) prologue): [row][c][eWq] / [o][PP] images, double buffered
+  // ---- DMA-pipelined variant (no act'(y) prologue): [row][c][eWq] / [o][PP] images, double buffered.
+  // CB = x channels per block: 64, or 32 when the patch is large (strided convs) or Cin is small.
   bool use_dma = (y_act == nullptr) && (g.tpg == 9 || g.tpg == 1) && jw >= 8;
   if (use_dma) {
     const bool y4 = (d->Wo % 4 == 0);
     const int PPh = y4 ? NPIX + 4 : NPIX + 1;
     g.eWq = g.eW | 1;
-    g.XSZ = jb * g.eH * 64 * g.eWq;
-    g.YSZ = 64 * PPh;
-    const size_t lds2 = sizeof(float) * 2 * ((size_t)((g.XSZ + 3) & ~3) + (size_t)((64 * PPh + 255) / 256) * 256);
     const unsigned long long xb = 4ull * d->B * d->Cin * d->Ti * d->Hi * d->Wi, yb = 4ull * d->B * d->Cout * d->To * d->Ho * d->Wo;
+    int CBh = d->Cin > 32 ? 64 : 32;
+    size_t lds2 = 0;
+    for (;;) {
+      g.XSZ = jb * g.eH * CBh * g.eWq;
+      lds2 = sizeof(float) * 2 * ((size_t)((g.XSZ + 3) & ~3) + (size_t)((64 * PPh + 255) / 256) * 256);
+      if (lds2 <= 160 * 1024 || CBh == 32) break;
+      CBh = 32;
+    }
+    g.YSZ = 64 * PPh;
     if (lds2 > 160 * 1024 || g.XSZ >= 65536 || xb >= 0xF0000000ull || yb >= 0xF0000000ull) use_dma = false;
     else {
       g.mg_ewq = magic_u16(g.eWq); g.mg_pp = magic_u16(PPh);
       g.x_bytes = (unsigned)xb; g.dy_bytes = (unsigned)yb;
       typedef void (*wk_t)(const WgradGeom);
-      wk_t kern = g.tpg == 9 ? (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true> : (wk_t)wgrad_dma_kernel<NPIX, 9, false>)
-                             : (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 1, true> : (wk_t)wgrad_dma_kernel<NPIX, 1, false>);
+      wk_t kern;
+      if (CBh == 64) kern = g.tpg == 9 ? (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 64> : (wk_t)wgrad_dma_kernel<NPIX, 9, false, 64>)
+                                       : (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 1, true, 64> : (wk_t)wgrad_dma_kernel<NPIX, 1, false, 64>);
+      else kern = g.tpg == 9 ? (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 32> : (wk_t)wgrad_dma_kernel<NPIX, 9, false, 32>)
+                             : (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 1, true, 32> : (wk_t)wgrad_dma_kernel<NPIX, 1, false, 32>);
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      int ns = 256 / (ncx * nco);        // LDS admits one (8-wave) block per CU
+      const int ncb = ceil_div(d->Cin, CBh);
+      int ns = 256 / (ncb * nco);        // LDS admits one (8-wave) block per CU
       if (ns < 1) ns = 1;
       if (ns > g.ntiles) ns = g.ntiles;
       for (int a = 0; a < d->kt; ++a) {
@@ -1037,8 +1052,8 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
         ga.nsplit = ns;
         ga.dwp = dwp + (size_t)a * g.tpg * d->Cin * g.CoPad;
         for (int b = 0; b < d->kh; ++b)
-          for (int c = 0; c < d->kw; ++c) ga.tap_offq[b * d->kw + c] = b * 64 * g.eWq + c;
-        hipLaunchKernelGGL(kern, dim3(ns, ncx, nco), dim3(512), lds2, s, ga);
+          for (int c = 0; c < d->kw; ++c) ga.tap_offq[b * d->kw + c] = b * CBh * g.eWq + c;
+        hipLaunchKernelGGL(kern, dim3(ns, ncb, nco), dim3(512), lds2, s, ga);
         if (int e = launch_status()) return e;
       }
     }
