@@ -14,34 +14,7 @@ import torch.nn as nn
 
 from . import ops
 from .modules.losses import ReconstructionLoss, discriminator_loss, generator_adv_loss
-
-
-class FlatParams:
-    """Re-homes the trainable parameters of `module` into one contiguous buffer (+ grad buffer)."""
-
-    def __init__(self, module: nn.Module):
-        self.params: List[nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
-        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
-        off = 0
-        for p in self.params:
-            k = p.numel()
-            self.flat[off:off + k].copy_(p.data.reshape(-1))
-            p.data = self.flat[off:off + k].view(p.shape)
-            p.grad = self.grad[off:off + k].view(p.shape)
-            off += k
-        self.n = n
-
-    def zero_grad(self):
-        self.grad.zero_()
-        off = 0
-        for p in self.params:       # autograd accumulates in place; re-attach if something replaced .grad
-            k = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
-                p.grad = self.grad[off:off + k].view(p.shape)
-            off += k
+from .parallel import FlatParams, allreduce_mean_, broadcast_module_state
 
 
 class FusedAdam:
@@ -67,12 +40,8 @@ class FusedAdam:
 
 
 def _allreduce_mean(buf: torch.Tensor, world: int):
-    """Flat-bucket gradient exchange: sum over ranks (RCCL on GPUs, gloo in CPU tests), then 1/world."""
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-    if buf.is_cuda:
-        ops.axpy_(buf, buf, 1.0 / world - 1.0)
-    else:
-        buf.mul_(1.0 / world)
+    """Flat-bucket gradient exchange; the 1/world scaling is the p2i_axpy kernel on GPUs."""
+    allreduce_mean_(buf, world, (lambda t, a: ops.axpy_(t, t, a - 1.0)) if buf.is_cuda else None)
 
 
 class TrainEngine:
@@ -99,14 +68,9 @@ class TrainEngine:
 
     def broadcast_state(self):
         """Rank 0's weights, spectral-norm u/v and frozen tensors to every rank, once."""
-        for net in (self.G, self.D):
-            if net is None:
-                continue
-            for t in list(net.buffers()) + [p.data for p in net.parameters() if not p.requires_grad]:
-                dist.broadcast(t, 0)
-        dist.broadcast(self.gp.flat, 0)
-        if self.dp is not None:
-            dist.broadcast(self.dp.flat, 0)
+        broadcast_module_state(self.G, self.gp)
+        if self.D is not None:
+            broadcast_module_state(self.D, self.dp)
 
     def train_step(self, frames, masked, masks) -> Dict[str, torch.Tensor]:
         """One iteration of train.py:240-326.  Returns 0-dim DEVICE tensors (no host sync here)."""

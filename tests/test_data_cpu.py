@@ -1,0 +1,57 @@
+"""Host-side data logic on CPU: mask semantics (sti_dataset.py:18-122), zarr-lite round trip, data module."""
+import numpy as np
+import torch
+
+
+def test_create_mask_semantics(tmp_path):
+    from p2igan_bench.data.sti_dataset import create_mask
+    v = torch.zeros(16, 32, 40, 1)
+    np.random.seed(0)
+    m = create_mask(v, "sti", block_sizes=[10])
+    assert m.shape == v.shape and torch.equal(m[0], m[15])
+    assert int(m[0].sum()) == 4 * 4                       # ceil(32/10) * ceil(40/10) cells, one pixel each
+    m = create_mask(v, "nowcasting", keep=4)
+    assert float(m[:4].min()) == 1 and float(m[4:].max()) == 0
+    np.random.seed(1)
+    m = create_mask(v, "fi", interval=[3])
+    assert [int(m[t].max()) for t in range(16)] == [1 if t % 4 == 0 else 0 for t in range(16)]
+    np.random.seed(2)
+    m = create_mask(v, "stin", block_sizes=[8], keep=2)
+    assert float(m[:2].min()) == 1 and int(m[5].sum()) == 4 * 5
+    f = tmp_path / "mask.txt"
+    mat = (np.random.rand(32, 40) > 0.9).astype(np.float32)
+    np.savetxt(f, mat)
+    m = create_mask(v, "stis", mask_file=str(f))
+    assert torch.equal(m[7, :, :, 0], torch.from_numpy(mat))
+
+
+def test_zarr_lite_roundtrip_and_train_store(tmp_path):
+    from p2igan_bench.data import zarr_lite
+    from p2igan_bench.data.dataloader import P2IDataModule
+    root = tmp_path / "train.zarr"
+    g = zarr_lite.Group(str(root), "w")
+    ev = g.require_group("events")
+    rng = np.random.default_rng(0)
+    for k in ("201801010000", "201801020000"):
+        e = ev.require_group(k)
+        e.create_dataset("frames", rng.integers(0, 255, (24, 40, 40), dtype=np.uint8), chunks=(20, 16, 16), compress=(k[-5] == "2"))
+    idx = np.array([[0, 0, 16], [0, 4, 16], [1, 8, 16], [1, 2, 16], [0, 8, 16]], dtype=np.int32)
+    g.require_group("index").create_dataset("windows", idx)
+    back = zarr_lite.Group(str(root))["events"]["201801020000"]["frames"]
+    assert back.shape == (24, 40, 40) and back[3:20, 5:33, 7].shape == (17, 28)
+    cfg = {"seed": 1, "data": {"train": {"data_root": str(root), "w": 32, "h": 32, "sample_length": 16, "mask": {"type": "sti", "block_sizes": [8]}}},
+           "train": {"batch_size": 2, "num_workers": 0}}
+    dm = P2IDataModule(cfg)
+    video, masked, mask = next(iter(dm.train_dataloader()))
+    assert video.shape == (2, 16, 32, 32, 1) and torch.equal(masked, video * mask)
+    assert len(dm.train_dataset) + len(dm.valid_dataset) == 5
+
+
+def test_synthetic_module_and_test_split_drops_sample_length():
+    from p2igan_bench.data.dataloader import P2IDataModule
+    cfg = {"data": {"train": {"data_root": "synthetic://4", "w": 32, "h": 32, "sample_length": 16, "mask": {"type": "sti", "block_sizes": [8]}},
+                    "test": {"data_root": "synthetic://2", "synthetic_length": 40, "sample_length": None}},
+           "train": {"batch_size": 2, "num_workers": 0}}
+    dm = P2IDataModule(cfg)
+    assert next(iter(dm.train_dataloader()))[0].shape == (2, 16, 32, 32, 1)
+    assert next(iter(dm.test_dataloader()))[0].shape == (1, 40, 32, 32, 1)
