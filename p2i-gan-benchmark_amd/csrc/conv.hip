@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(const PatchGeom g) {
 // wave-base + lane*size), hence the unpadded patch pitch eW and channel stride CSl.
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int MB, int NPIX, int WAVES_M, int CK>
+template <int MB, int NPIX, int WAVES_M, int CK, int NT>
 __global__ __launch_bounds__(256) void patch_gemm_dma_kernel(const PatchGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -312,30 +312,42 @@ __global__ __launch_bounds__(256) void patch_gemm_dma_kernel(const PatchGeom g) 
     }
   };
 
+  int toffs[NT > 0 ? NT : 1];
+  if constexpr (NT > 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) toffs[t] = g.tap_off[t];
+  }
   const int nchunks = (g.Ck + CK - 1) / CK;
   issue(0, buf0);
   for (int k = 0; k < nchunks; ++k) {
     __syncthreads();                                 // chunk k landed (vmcnt(0) + barrier); buffer (k+1)&1 is free
     float* cur = buf0 + (k & 1) * BUFSZ;
     if (k + 1 < nchunks) issue((k + 1) * CK, buf0 + ((k + 1) & 1) * BUFSZ);
-    const float* lw = cur;
+    const float* lw = cur + lhi * MB + wm * TM * 32 + l31;
     const float* lp = cur + WSZ;
-    for (int tap = 0; tap < g.ntaps; ++tap) {
-      const int toff = g.tap_off[tap];
-      const float* wt = lw + tap * CK * MB + lhi * MB + wm * TM * 32 + l31;
+    // one tap: all CK/2 channel pairs' operands are fetched first (TM + TN ds_read_b32 per pair), then the MFMAs
+    auto do_tap = [&](int tap, int toff) {
+      float a[CK / 2][TM], bv[CK / 2][TN];
 #pragma unroll
       for (int cp = 0; cp < CK / 2; ++cp) {
-        float a[TM], bv[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = wt[cp * 2 * MB + i * 32];
+        for (int i = 0; i < TM; ++i) a[cp][i] = lw[tap * CK * MB + cp * 2 * MB + i * 32];
 #pragma unroll
-        for (int f = 0; f < TN; ++f) bv[f] = lp[lane_base[f] + toff + cp * 2 * g.CSl];
+        for (int f = 0; f < TN; ++f) bv[cp][f] = lp[lane_base[f] + toff + cp * 2 * g.CSl];
+      }
+#pragma unroll
+      for (int cp = 0; cp < CK / 2; ++cp)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int f = 0; f < TN; ++f)
-            acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[f], acc[i][f], 0, 0, 0);
-      }
+            acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp][i], bv[cp][f], acc[i][f], 0, 0, 0);
+    };
+    if constexpr (NT > 0) {
+#pragma unroll
+      for (int tap = 0; tap < NT; ++tap) do_tap(tap, toffs[tap]);
+    } else {
+      for (int tap = 0; tap < g.ntaps; ++tap) do_tap(tap, g.tap_off[tap]);
     }
   }
 
@@ -680,9 +692,9 @@ static int launch_patch(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s
   return launch_status();
 }
 
-template <int MB, int NPIX, int WM, int CK>
-static int launch_patch_dma(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
-  auto k = patch_gemm_dma_kernel<MB, NPIX, WM, CK>;
+template <int MB, int NPIX, int WM, int CK, int NT>
+static int launch_patch_dma_nt(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
+  auto k = patch_gemm_dma_kernel<MB, NPIX, WM, CK, NT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -690,6 +702,15 @@ static int launch_patch_dma(const PatchGeom& g, dim3 grid, size_t lds, hipStream
   }
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, g);
   return launch_status();
+}
+template <int MB, int NPIX, int WM, int CK>
+static int launch_patch_dma(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
+  if (g.ntaps == 9) return launch_patch_dma_nt<MB, NPIX, WM, CK, 9>(g, grid, lds, s);
+  if (g.ntaps == 1) return launch_patch_dma_nt<MB, NPIX, WM, CK, 1>(g, grid, lds, s);
+  if constexpr (CK <= 4) {
+    if (g.ntaps == 27) return launch_patch_dma_nt<MB, NPIX, WM, CK, 27>(g, grid, lds, s);
+  }
+  return launch_patch_dma_nt<MB, NPIX, WM, CK, 0>(g, grid, lds, s);
 }
 
 static int dispatch_patch_dma(const TileCfg& c, const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
