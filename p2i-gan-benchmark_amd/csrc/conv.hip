@@ -206,8 +206,11 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(const PatchGeom g) {
 // wave-base + lane*size), hence the unpadded patch pitch eW and channel stride CSl.
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int MB, int NPIX, int WAVES_M, int CK, int NT>
-__global__ __launch_bounds__(256) void patch_gemm_dma_kernel(const PatchGeom g) {
+// KG = 2: 8-wave workgroups; wave group kg multiplies half of each chunk's channel pairs (intra-block
+// split-K, partial tiles combined through LDS before the epilogue) so that a launch with only ~1 workgroup
+// per CU still has two waves per SIMD to hide DMA issue, LDS latency and barrier skew.
+template <int MB, int NPIX, int WAVES_M, int CK, int NT, int KG>
+__global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int TM = MB / (32 * WAVES_M);
@@ -222,7 +225,8 @@ __global__ __launch_bounds__(256) void patch_gemm_dma_kernel(const PatchGeom g) 
   float* buf0 = smem + wtab_sz + PTp;                // [2][WSZ + PTp]
   const int BUFSZ = WSZ + PTp;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NTH = 256 * KG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kg = tid >> 8;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, lhi = lane >> 5;
 
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void patch_gemm_dma_kernel(const PatchGeom g) 
   const int src_t0 = j0t * g.mT + g.bT, src_h0 = j0h * g.mH + g.bH, src_w0 = j0w * g.mW + g.bW;
 
   // ---- offset tables (bytes; 0xFFFFFFFC = out of range -> DMA writes 0)
-  for (int r = tid; r < wtab_sz; r += 256) {
+  for (int r = tid; r < wtab_sz; r += NTH) {
     int off = -4;
     if (r < nwrows) {
       const int tap = r / CK, c = r - tap * CK;
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256) void patch_gemm_dma_kernel(const PatchGeom g) 
     }
     wtab[r] = off;
   }
-  for (int e = tid; e < PTp; e += 256) {
+  for (int e = tid; e < PTp; e += NTH) {
     int off = -4;
     if (e < g.PT) {
       const int c = fast_div(e, g.mg_csl);
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256) void patch_gemm_dma_kernel(const PatchGeom g) 
 
   auto issue = [&](int c0, float* buf) {
     const int w_soff = c0 * g.CmPad * 4;
-    for (int f0 = 0; f0 < nwv; f0 += 256) {          // weights: 16 B per lane
+    for (int f0 = 0; f0 < nwv; f0 += NTH) {          // weights: 16 B per lane
       const int f = f0 + tid;
       int voff = -4;
       if (f < nwv) {
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(256) void patch_gemm_dma_kernel(const PatchGeom g) 
     }
     float* pb = buf + WSZ;
     const int p_soff = c0 * chan_bytes;
-    for (int e0 = 0; e0 < PTp; e0 += 256) {          // patch: 4 B per lane
+    for (int e0 = 0; e0 < PTp; e0 += NTH) {          // patch: 4 B per lane
       const int e = e0 + tid;
       const int voff = e < PTp ? ptab[e] : -4;
       if (e0 + wbase < PTp)
@@ -327,16 +331,17 @@ __global__ __launch_bounds__(256) void patch_gemm_dma_kernel(const PatchGeom g) 
     const float* lp = cur + WSZ;
     // one tap: all CK/2 channel pairs' operands are fetched first (TM + TN ds_read_b32 per pair), then the MFMAs
     auto do_tap = [&](int tap, int toff) {
-      float a[CK / 2][TM], bv[CK / 2][TN];
+      constexpr int NCP = CK / 2 / KG;               // channel pairs of this wave group
+      float a[NCP][TM], bv[NCP][TN];
 #pragma unroll
-      for (int cp = 0; cp < CK / 2; ++cp) {
+      for (int cp = 0; cp < NCP; ++cp) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[cp][i] = lw[tap * CK * MB + cp * 2 * MB + i * 32];
+        for (int i = 0; i < TM; ++i) a[cp][i] = lw[tap * CK * MB + (kg * NCP + cp) * 2 * MB + i * 32];
 #pragma unroll
-        for (int f = 0; f < TN; ++f) bv[cp][f] = lp[lane_base[f] + toff + cp * 2 * g.CSl];
+        for (int f = 0; f < TN; ++f) bv[cp][f] = lp[lane_base[f] + toff + (kg * NCP + cp) * 2 * g.CSl];
       }
 #pragma unroll
-      for (int cp = 0; cp < CK / 2; ++cp)
+      for (int cp = 0; cp < NCP; ++cp)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -351,6 +356,26 @@ __global__ __launch_bounds__(256) void patch_gemm_dma_kernel(const PatchGeom g) 
     }
   }
 
+  if constexpr (KG == 2) {                           // combine the two wave groups' partial tiles through LDS
+    __syncthreads();
+    float* red = smem + ((wave * TM * TN * 16) << 6) + lane;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int f = 0; f < TN; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((i * TN + f) * 16 + r) << 6] = acc[i][f][r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int f = 0; f < TN; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][f][r] += red[((i * TN + f) * 16 + r) << 6];
+  }
   const int dHW = g.dH * g.dW;
 #pragma unroll
   for (int f = 0; f < TN; ++f) {
@@ -692,43 +717,55 @@ static int launch_patch(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s
   return launch_status();
 }
 
-template <int MB, int NPIX, int WM, int CK, int NT>
+template <int MB, int NPIX, int WM, int CK, int NT, int KG>
 static int launch_patch_dma_nt(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
-  auto k = patch_gemm_dma_kernel<MB, NPIX, WM, CK, NT>;
+  auto k = patch_gemm_dma_kernel<MB, NPIX, WM, CK, NT, KG>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, g);
+  hipLaunchKernelGGL(k, grid, dim3(256 * KG), lds, s, g);
   return launch_status();
 }
-template <int MB, int NPIX, int WM, int CK>
+template <int MB, int NPIX, int WM, int CK, int KG>
 static int launch_patch_dma(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
-  if (g.ntaps == 9) return launch_patch_dma_nt<MB, NPIX, WM, CK, 9>(g, grid, lds, s);
-  if (g.ntaps == 1) return launch_patch_dma_nt<MB, NPIX, WM, CK, 1>(g, grid, lds, s);
-  if constexpr (CK <= 4) {
-    if (g.ntaps == 27) return launch_patch_dma_nt<MB, NPIX, WM, CK, 27>(g, grid, lds, s);
+  if constexpr (CK <= 8) {
+    if (g.ntaps == 9) return launch_patch_dma_nt<MB, NPIX, WM, CK, 9, KG>(g, grid, lds, s);
   }
-  return launch_patch_dma_nt<MB, NPIX, WM, CK, 0>(g, grid, lds, s);
+  if (g.ntaps == 1) return launch_patch_dma_nt<MB, NPIX, WM, CK, 1, KG>(g, grid, lds, s);
+  if constexpr (CK <= 4 && KG == 1) {
+    if (g.ntaps == 27) return launch_patch_dma_nt<MB, NPIX, WM, CK, 27, KG>(g, grid, lds, s);
+  }
+  return launch_patch_dma_nt<MB, NPIX, WM, CK, 0, KG>(g, grid, lds, s);
 }
 
-static int dispatch_patch_dma(const TileCfg& c, const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
-#define P2I_CASE(mb_, npix_, wm_, ck_) \
-  if (c.MB == mb_ && c.NPIX == npix_ && c.WM == wm_ && c.CK == ck_) return launch_patch_dma<mb_, npix_, wm_, ck_>(g, grid, lds, s);
-  P2I_CASE(128, 256, 2, 8)
-  P2I_CASE(64, 256, 1, 8)
-  P2I_CASE(128, 128, 2, 8)
-  P2I_CASE(64, 128, 2, 8)
-  P2I_CASE(32, 128, 1, 8)
-  P2I_CASE(128, 256, 2, 4)
-  P2I_CASE(64, 256, 1, 4)
-  P2I_CASE(64, 128, 2, 4)
-  P2I_CASE(32, 128, 1, 4)
-  P2I_CASE(64, 128, 2, 2)
-  P2I_CASE(32, 128, 1, 2)
+static int dispatch_patch_dma(const TileCfg& c, int KG, const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
+#define P2I_CASE(mb_, npix_, wm_, ck_, kg_) \
+  if (c.MB == mb_ && c.NPIX == npix_ && c.WM == wm_ && c.CK == ck_ && KG == kg_) return launch_patch_dma<mb_, npix_, wm_, ck_, kg_>(g, grid, lds, s);
+  P2I_CASE(128, 256, 2, 8, 1)
+  P2I_CASE(64, 256, 1, 8, 1)
+  P2I_CASE(128, 128, 2, 8, 1)
+  P2I_CASE(64, 128, 2, 8, 1)
+  P2I_CASE(32, 128, 1, 8, 1)
+  P2I_CASE(64, 256, 1, 8, 2)
+  P2I_CASE(64, 128, 2, 8, 2)
+  P2I_CASE(32, 128, 1, 8, 2)
+  P2I_CASE(128, 256, 2, 16, 1)
+  P2I_CASE(64, 256, 1, 16, 1)
+  P2I_CASE(64, 128, 2, 16, 1)
+  P2I_CASE(32, 128, 1, 16, 1)
+  P2I_CASE(64, 256, 1, 16, 2)
+  P2I_CASE(64, 128, 2, 16, 2)
+  P2I_CASE(32, 128, 1, 16, 2)
+  P2I_CASE(128, 256, 2, 4, 1)
+  P2I_CASE(64, 256, 1, 4, 1)
+  P2I_CASE(64, 128, 2, 4, 1)
+  P2I_CASE(32, 128, 1, 4, 1)
+  P2I_CASE(64, 128, 2, 2, 1)
+  P2I_CASE(32, 128, 1, 2, 1)
 #undef P2I_CASE
-  set_error("no DMA kernel instance for tile cfg %d %d %d %d", c.MB, c.NPIX, c.WM, c.CK);
+  set_error("no DMA kernel instance for tile cfg %d %d %d %d kg %d", c.MB, c.NPIX, c.WM, c.CK, KG);
   return P2I_EINVAL;
 }
 
@@ -804,10 +841,10 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
       t.rpc = jb * t.eth;
       t.CSl = t.rpc * t.eW;
       t.CS = t.CSl;
-      for (int CKc = 8; CKc >= 2; CKc >>= 1) {
+      for (int CKc = (cs.ntaps <= 4 ? 16 : 8); CKc >= 2; CKc >>= 1) {
         if (g.Ck >= CKc ? (g.Ck % CKc != 0) : (CKc != 2 && g.Ck * 2 <= CKc)) continue;
         if (CKc == 2 && !(MBc == 64 && NP == 128) && !(MBc == 32)) continue;      // instantiated CK=2 tiles
-        if (CKc == 4 && MBc == 128 && NP == 128) continue;
+        if ((CKc == 4 || CKc == 16) && MBc == 128 && NP == 128) continue;
         const int PT = CKc * t.CSl;
         if (PT >= 65536 || t.CSl >= 65536) continue;
         const int PTp = (PT + 63) & ~63;
@@ -838,8 +875,13 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
         bg.tap_w[i] = cs.tw[i];
         bg.tap_off[i] = ((cs.dt[i] - lo[0]) * bg.eH + (cs.dh[i] - lo[1])) * bg.eW + (cs.dw[i] - lo[2]);
       }
+      // ~1 workgroup per CU or fewer: 8-wave workgroups with intra-block split-K (small accumulator tiles only)
+      const long long nb = (long long)best_grid.x * best_grid.y;
+      const int acc_regs = (c.MB / 32) * (c.NPIX / 32) / 4 * 16;
+      const size_t red_bytes = (size_t)4 * acc_regs * 64 * 4;
+      const int KG = (nb <= 320 && c.CK >= 8 && c.MB <= 64 && red_bytes <= best_lds) ? 2 : 1;
       g_last_plan[0] = c.MB; g_last_plan[1] = c.NPIX; g_last_plan[2] = c.WM; g_last_plan[3] = c.CK;
-      return dispatch_patch_dma(c, bg, best_grid, best_lds, s);
+      return dispatch_patch_dma(c, KG, bg, best_grid, best_lds, s);
     }
   }
 
