@@ -16,7 +16,41 @@ void set_error(const char* fmt, ...) {
 
 __device__ __forceinline__ int pad32(int v) { return (v + 31) & ~31; }
 
-// ---- DO-Conv fold.  One thread per flat pair q = o'*I + i of the (O/g, I, 9) view.
+// ---- DO-Conv fold.  One thread per flat pair q = o'*I + i of the (O/g, I, 9) view; a block owns a
+// 16 (o') x 16 (i) tile so that BOTH packed layouts are written in 64-B runs (wp_f: o contiguous,
+// wp_d: cin contiguous) via an LDS transpose.  groups == 1 only; grouped / 1x1 layers use the simple kernel.
+__global__ __launch_bounds__(256) void fold_fwd_tile_kernel(const float* __restrict__ W, const float* __restrict__ D,
+                                                           const float* __restrict__ Dd, int O, int I, float* wp_f, float* wp_d) {
+  __shared__ float tile[9][16][17];
+  const int ti = threadIdx.x & 15, to = threadIdx.x >> 4;     // thread computes (o' = o0+to, i = i0+ti): W reads 36-B runs
+  const int o0 = blockIdx.y * 16, i0 = blockIdx.x * 16;
+  const int o = o0 + to, i = i0 + ti;
+  if (o < O && i < I) {
+    float w[9];
+    const float* wq = W + ((size_t)o * I + i) * 9;
+#pragma unroll
+    for (int s2 = 0; s2 < 9; ++s2) w[s2] = wq[s2];
+    const float* d = D + (size_t)i * 81;
+    const float* dd = Dd + (size_t)i * 81;
+#pragma unroll
+    for (int m = 0; m < 9; ++m) {
+      float acc = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 9; ++s2) acc += (d[m * 9 + s2] + dd[m * 9 + s2]) * w[s2];
+      tile[m][to][ti] = acc;
+    }
+  }
+  __syncthreads();
+  const int a = threadIdx.x & 15, b = threadIdx.x >> 4;
+#pragma unroll
+  for (int m = 0; m < 9; ++m) {
+    // wp_f[m][i][o]: lanes along o
+    if (i0 + b < I && o0 + a < O) wp_f[((size_t)m * I + i0 + b) * O + o0 + a] = tile[m][a][b];
+    // wp_d[m][o][i]: lanes along i
+    if (wp_d && o0 + b < O && i0 + a < I) wp_d[((size_t)m * O + o0 + b) * I + i0 + a] = tile[m][b][a];
+  }
+}
+
 __global__ void fold_fwd_kernel(const float* __restrict__ W, const float* __restrict__ D, const float* __restrict__ Dd,
                                 int O, int I, int groups, int ksz, int identity_rep, float* wp_f, float* wp_d) {
   const int Ig = I / groups, Og = O / groups;
@@ -46,6 +80,34 @@ __global__ void fold_fwd_kernel(const float* __restrict__ W, const float* __rest
     if (identity_rep > 0 && m == 4 && cin == o / identity_rep) acc += 1.f;   // + x.repeat_interleave(rep,1), p2igan.py:79
     wp_f[((size_t)m * I + cin) * Opad + o] = acc;
     if (wp_d) wp_d[((size_t)m * O + o) * Ipad + cin] = acc;
+  }
+}
+
+// dW[o'][i][s] = sum_m dDoW[o',i,m] (D+Dd)[i][m][s] for groups == 1: dDoW tile gathered with o-contiguous reads
+__global__ __launch_bounds__(256) void fold_bwd_w_tile_kernel(const float* __restrict__ dwp, const float* __restrict__ D,
+                                                             const float* __restrict__ Dd, int O, int I, float* dW) {
+  __shared__ float tile[9][16][17];
+  const int o0 = blockIdx.y * 16, i0 = blockIdx.x * 16;
+  const int a = threadIdx.x & 15, b = threadIdx.x >> 4;
+#pragma unroll
+  for (int m = 0; m < 9; ++m)
+    tile[m][a][b] = (i0 + b < I && o0 + a < O) ? dwp[((size_t)m * I + i0 + b) * O + o0 + a] : 0.f;    // [m][o][i]
+  __syncthreads();
+  const int ti = threadIdx.x & 15, to = threadIdx.x >> 4;
+  const int o = o0 + to, i = i0 + ti;
+  if (o >= O || i >= I) return;
+  float g[9];
+#pragma unroll
+  for (int m = 0; m < 9; ++m) g[m] = tile[m][to][ti];
+  const float* d = D + (size_t)i * 81;
+  const float* dd = Dd + (size_t)i * 81;
+  float* out = dW + ((size_t)o * I + i) * 9;
+#pragma unroll
+  for (int s2 = 0; s2 < 9; ++s2) {
+    float acc = 0.f;
+#pragma unroll
+    for (int m = 0; m < 9; ++m) acc += g[m] * (d[m * 9 + s2] + dd[m * 9 + s2]);
+    out[s2] = acc;
   }
 }
 
@@ -143,12 +205,22 @@ __global__ void unpack_kernel(const float* __restrict__ dwp, int O, int I, int N
 }
 
 // ---- spectral norm
-__global__ void sn_wtu_kernel(const float* __restrict__ w, const float* __restrict__ u, int O, int K, float* t) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
+// t[k] += sum_{o in slab} W[o][k] u[o]; grid (K/64, O/32); block 256 = 64 columns x 4 row groups (t zeroed by caller)
+__global__ __launch_bounds__(256) void sn_wtu_kernel(const float* __restrict__ w, const float* __restrict__ u, int O, int K, float* t) {
+  __shared__ float part[4][64];
+  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + col, o0 = blockIdx.y * 32 + rg * 8;
   float acc = 0.f;
-  for (int o = 0; o < O; ++o) acc += w[(size_t)o * K + k] * u[o];
-  t[k] = acc;
+  if (k < K) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int o = o0 + r;
+      if (o < O) acc += w[(size_t)o * K + k] * u[o];
+    }
+  }
+  part[rg][col] = acc;
+  __syncthreads();
+  if (rg == 0 && k < K) atomicAdd(t + k, part[0][col] + part[1][col] + part[2][col] + part[3][col]);
 }
 __global__ void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ v, int O, int K, float* s) {
   const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -199,6 +271,10 @@ extern "C" int p2i_doconv_fold_fwd(const float* W, const float* D, const float* 
   const int nt = ksz * ksz, Opad = (O + 31) / 32 * 32, Ipad = (I + 31) / 32 * 32;
   if (groups > 1 || Opad != O) (void)hipMemsetAsync(wp_f, 0, sizeof(float) * (size_t)nt * I * Opad, s);
   if (wp_d && (groups > 1 || Ipad != I)) (void)hipMemsetAsync(wp_d, 0, sizeof(float) * (size_t)nt * O * Ipad, s);
+  if (ksz == 3 && groups == 1 && identity_rep == 0 && Opad == O && Ipad == I) {
+    hipLaunchKernelGGL(fold_fwd_tile_kernel, dim3(ceil_div(I, 16), ceil_div(O, 16)), dim3(256), 0, s, W, D, D_diag, O, I, wp_f, wp_d);
+    return launch_status();
+  }
   const int n = (ksz == 1) ? O * (I / groups) : (O / groups) * I;
   hipLaunchKernelGGL(fold_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, W, D, D_diag, O, I, groups, ksz, identity_rep, wp_f, wp_d);
   return launch_status();
@@ -210,7 +286,10 @@ extern "C" int p2i_doconv_fold_bwd(const float* dwp_f, const float* W, const flo
   P2I_REQUIRE(ksz == 1 || (D && D_diag && dD), "3x3 DO-Conv needs D, D_diag, dD");
   hipStream_t s = (hipStream_t)stream;
   const int n = (ksz == 1) ? O * (I / groups) : (O / groups) * I;
-  hipLaunchKernelGGL(fold_bwd_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dwp_f, D, D_diag, O, I, groups, ksz, dW);
+  if (ksz == 3 && groups == 1 && O % 32 == 0)
+    hipLaunchKernelGGL(fold_bwd_w_tile_kernel, dim3(ceil_div(I, 16), ceil_div(O, 16)), dim3(256), 0, s, dwp_f, D, D_diag, O, I, dW);
+  else
+    hipLaunchKernelGGL(fold_bwd_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dwp_f, D, D_diag, O, I, groups, ksz, dW);
   if (ksz == 3) hipLaunchKernelGGL(fold_bwd_d_kernel, dim3(I), dim3(256), 0, s, dwp_f, W, O, I, groups, dD);
   return launch_status();
 }
@@ -247,7 +326,8 @@ extern "C" int p2i_spectral_norm(const float* w, int O, int K, float* u, float* 
   float* t = scratch;        // K
   float* sv = scratch + K;   // O
   if (training) {
-    hipLaunchKernelGGL(sn_wtu_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, s, w, u, O, K, t);
+    (void)hipMemsetAsync(t, 0, sizeof(float) * K, s);
+    hipLaunchKernelGGL(sn_wtu_kernel, dim3(ceil_div(K, 64), ceil_div(O, 32)), dim3(256), 0, s, w, u, O, K, t);
     hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, t, K, v, (float*)nullptr);
     hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(O, 4)), dim3(256), 0, s, w, v, O, K, sv);
     hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, sv, O, u, sigma);

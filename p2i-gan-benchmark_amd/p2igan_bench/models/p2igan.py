@@ -120,6 +120,20 @@ class P2IGenerator(nn.Module):
             init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
             init.constant_(m.bias.data, 0.0)
 
+    def _arena_numel(self) -> int:
+        """Floats of all packed weight / bias gradients one backward pass accumulates into."""
+        if not hasattr(self, "_arena_n"):
+            n = 0
+            for lvl in range(4):
+                ch = BASE_CH << lvl
+                n += 2 * self.num_res * 9 * ch * ops.pad32(ch)
+            for up in self.UP:
+                co, ci = up.proj.weight.shape[0], up.proj.weight.shape[1]
+                n += ci * ops.pad32(co) + co + 8
+            n += 9 * self.length * ops.pad32(BASE_CH) + BASE_CH * ops.pad32(self.length) + 64
+            self._arena_n = n
+        return self._arena_n
+
     def forward(self, masked_frames, masks):
         params = [p for _, p in self.named_parameters()]
         return _GeneratorFn.apply(self, masked_frames, masks, *params)
@@ -201,11 +215,12 @@ class _GeneratorFn(torch.autograd.Function):
         net, S = ctx.net, ctx.S
         b, t, h, w = S["shape"]
         grads = {}
+        arena = ops.ZeroArena(net._arena_numel(), dout.device)
         dz = dout.reshape(b, t, h, w).contiguous().float()
         # ---- ConvsOut (grouped 1x1, dense-lowered) + tanh
         spec_out = _spec2d(BASE_CH, t, 1)
         cout = _doconv_of(net.ConvsOut[0])
-        dwp, _ = ops.conv_wgrad(spec_out, S["h0"], dz, S["z"], ACT_TANH)
+        dwp, _ = ops.conv_wgrad(spec_out, S["h0"], dz, S["z"], ACT_TANH, arena=arena)
         grads[id(cout.W)], _ = ops.doconv_fold_bwd(dwp, *cout.tensors(), t, BASE_CH, 4, 1)
         dh = ops.conv_dgrad(spec_out, dz, S["wp_out_d"], tuple(S["h0"].shape), S["z"], ACT_TANH)
 
@@ -215,10 +230,10 @@ class _GeneratorFn(torch.autograd.Function):
             blocks = net.Decoder[lvl].layers
             for rb, (hin, y1, w1d, w2d) in zip(reversed(list(blocks)), reversed(S["rec"][lvl])):
                 c1, c2 = _doconv_of(rb.main[0]), _doconv_of(rb.main[1])
-                dwp2, _ = ops.conv_wgrad(spec, y1, dh)
+                dwp2, _ = ops.conv_wgrad(spec, y1, dh, arena=arena)
                 grads[id(c2.W)], grads[id(c2.D)] = ops.doconv_fold_bwd(dwp2, *c2.tensors(), ch, ch, 1, 3)
                 dy1 = ops.conv_dgrad(spec, dh, w2d, tuple(y1.shape), mask_y=y1, mask_act=ACT_RELU)   # * relu'(y1) fused
-                dwp1, _ = ops.conv_wgrad(spec, hin, dy1)
+                dwp1, _ = ops.conv_wgrad(spec, hin, dy1, arena=arena)
                 grads[id(c1.W)], grads[id(c1.D)] = ops.doconv_fold_bwd(dwp1, *c1.tensors(), ch, ch, 1, 3)
                 dh = ops.conv_dgrad(spec, dy1, w1d, tuple(hin.shape), add=dh)                     # + skip path
             return dh
@@ -228,7 +243,7 @@ class _GeneratorFn(torch.autograd.Function):
             hin, u, r, wpd = S["up"][i]
             cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
             spec = _spec2d(cin_, cout_, 1)
-            dwp, db = ops.conv_wgrad(spec, u, dr, r, ACT_RELU, want_bias=True)
+            dwp, db = ops.conv_wgrad(spec, u, dr, r, ACT_RELU, want_bias=True, arena=arena)
             grads[id(up.proj.weight)] = ops.weight_unpack_grad(dwp, up.proj.weight.reshape(cout_, cin_, 1)).reshape(up.proj.weight.shape)
             grads[id(up.proj.bias)] = db
             du = ops.conv_dgrad(spec, dr, wpd, tuple(u.shape), r, ACT_RELU)
@@ -249,7 +264,7 @@ class _GeneratorFn(torch.autograd.Function):
         # ---- Convsin (grouped 3x3 + repeat_interleave skip, dense-lowered with centre identity)
         spec_in = _spec2d(t, BASE_CH, 3)
         cin = _doconv_of(net.Convsin[0])
-        dwp, _ = ops.conv_wgrad(spec_in, S["idw"], dx_)
+        dwp, _ = ops.conv_wgrad(spec_in, S["idw"], dx_, arena=arena)
         grads[id(cin.W)], grads[id(cin.D)] = ops.doconv_fold_bwd(dwp, *cin.tensors(), BASE_CH, t, 4, 3)
         didw = ops.conv_dgrad(spec_in, dx_, S["wp_in_d"], tuple(S["idw"].shape))
         da = ops.idw_bwd(didw, S["sel"])
@@ -371,6 +386,10 @@ class _DiscriminatorFn(torch.autograd.Function):
         o2, o3 = r2[-1]["y"], r3[-1]["y"]
         d2, d3, da = ops.dtail_bwd(o2, tuple(o3.shape), net.alpha2d.reshape(1), dfused.contiguous().float(), need_alpha=need_alpha)
         gw, gb = {}, {}
+        arena = None
+        if any(needs[:2 * nl]):
+            tot = sum(sp.ntaps * sp.cin * ops.pad32(sp.cout) + sp.cout + 8 for sp in net.specs2d + net.specs3d)
+            arena = ops.ZeroArena(tot, dfused.device)
 
         def branch_bwd(layers, specs, recs, dy, base, first_add=None):
             # dy arrives already multiplied by act'(y_n): the dgrad of layer n+1 applies it in its epilogue
@@ -378,7 +397,7 @@ class _DiscriminatorFn(torch.autograd.Function):
             for n in reversed(range(len(layers))):
                 m, spec, rc = layers[n], specs[n], recs[n]
                 if needs[2 * (base + n)] or needs[2 * (base + n) + 1]:
-                    dwp, db = ops.conv_wgrad(spec, rc["x"], dy, want_bias=True)
+                    dwp, db = ops.conv_wgrad(spec, rc["x"], dy, want_bias=True, arena=arena)
                     wo = m.weight_orig
                     wflat = wo.reshape(wo.shape[0], wo.shape[1], -1)
                     gw[base + n] = ops.weight_unpack_grad(dwp, wflat, wflat, rc["sigma"], rc["u"], rc["v"]).reshape(wo.shape)

@@ -166,7 +166,27 @@ def conv_dgrad(spec: ConvSpec, dy, wp_d, in_shape, y_act=None, act=ACT_NONE, add
     return dx
 
 
-def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False):
+class ZeroArena:
+    """One zero-filled buffer carved into the (atomically accumulated) gradient outputs of a backward pass:
+    a single memset instead of one fill kernel per weight tensor."""
+
+    def __init__(self, numel: int, device):
+        self.buf = torch.zeros(numel, device=device, dtype=torch.float32)
+        self.off = 0
+
+    def take(self, shape):
+        n = 1
+        for d in shape:
+            n *= d
+        n4 = (n + 3) // 4 * 4                       # keep every carve 16-B aligned
+        if self.off + n4 > self.buf.numel():
+            return torch.zeros(shape, device=self.buf.device, dtype=torch.float32)
+        t = self.buf[self.off:self.off + n].view(shape)
+        self.off += n4
+        return t
+
+
+def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False, arena: Optional["ZeroArena"] = None):
     """Packed weight gradient dwp_f [ntaps][cin][pad32(cout)] (+ bias gradient)."""
     lib = _hip.load()
     b, c, t, h, w = _dims5(x)
@@ -176,8 +196,12 @@ def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False)
         raise RuntimeError(f"conv_wgrad: shape mismatch dy={tuple(dy.shape)} expected {eshape}")
     if y_act is not None and y_act.shape != dy.shape:
         raise RuntimeError("conv_wgrad: y_act shape mismatch")
-    dwp = torch.zeros(spec.wp_f_shape(), device=x.device, dtype=torch.float32)
-    db = torch.zeros(spec.cout, device=x.device, dtype=torch.float32) if want_bias else None
+    if arena is not None:
+        dwp = arena.take(spec.wp_f_shape())
+        db = arena.take((spec.cout,)) if want_bias else None
+    else:
+        dwp = torch.zeros(spec.wp_f_shape(), device=x.device, dtype=torch.float32)
+        db = torch.zeros(spec.cout, device=x.device, dtype=torch.float32) if want_bias else None
     _chk(x, dy, y_act, dwp, db)
     d = spec.desc(b, t, h, w)
     e0 = _prof_begin()
