@@ -280,14 +280,16 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][f][r] = 0.f;
 
-  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.src), 0, g.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.wp), 0, g.wp_bytes, 0x00020000);
+  const v4i32 rs_src = make_rsrc(g.src, g.src_bytes);
+  const v4i32 rs_w = make_rsrc(g.wp, g.wp_bytes);
+  const unsigned smem_la = lds_base(smem);
+  const int buf0_off = (int)(buf0 - smem);
   const int chan_bytes = g.sT * sHW * 4;             // source bytes per channel
   const int wbase = tid & ~63;                       // wave-uniform part of this thread's linear index
   const int nwv = nwrows * V;                        // float4 per chunk
   __syncthreads();                                   // tables visible
 
-  auto issue = [&](int c0, float* buf) {
+  auto issue = [&](int c0, int bufoff) {                 // bufoff: float offset of the target buffer inside smem
     const int w_soff = c0 * g.CmPad * 4;
     for (int f0 = 0; f0 < nwv; f0 += NTH) {          // weights: 16 B per lane
       const int f = f0 + tid;
@@ -298,15 +300,15 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
         voff = base < 0 ? -4 : base + col4 * 16;
       }
       if (f0 + wbase < ((nwv + 63) & ~63))   // whole waves past the padded weight area must not write (they would zero the patch)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(buf + (f0 + wbase) * 4), 16, voff, w_soff, 0, 0);
+        dma_b128(rs_w, smem_la + 4u * (bufoff + (f0 + wbase) * 4), voff, w_soff);
     }
-    float* pb = buf + WSZ;
+    const int pbo = bufoff + WSZ;
     const int p_soff = c0 * chan_bytes;
     for (int e0 = 0; e0 < PTp; e0 += NTH) {          // patch: 4 B per lane
       const int e = e0 + tid;
       const int voff = e < PTp ? ptab[e] : -4;
       if (e0 + wbase < PTp)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(pb + e0 + wbase), 4, voff, p_soff, 0, 0);
+        dma_b32(rs_src, smem_la + 4u * (pbo + e0 + wbase), voff, p_soff);
     }
   };
 
@@ -316,37 +318,66 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
     for (int t = 0; t < NT; ++t) toffs[t] = g.tap_off[t];
   }
   const int nchunks = (g.Ck + CK - 1) / CK;
-  issue(0, buf0);
+  issue(0, buf0_off);
   for (int k = 0; k < nchunks; ++k) {
-    __syncthreads();                                 // chunk k landed (vmcnt(0) + barrier); buffer (k+1)&1 is free
+    dma_wait_all();                                  // this wave's DMA share of chunk k has landed ...
+    __syncthreads();                                 // ... and everybody else's; buffer (k+1)&1 is free
     float* cur = buf0 + (k & 1) * BUFSZ;
-    if (k + 1 < nchunks) issue((k + 1) * CK, buf0 + ((k + 1) & 1) * BUFSZ);
+    if (k + 1 < nchunks) issue((k + 1) * CK, buf0_off + ((k + 1) & 1) * BUFSZ);
     const float* lw = cur + lhi * MB + wm * TM * 32 + l31;
     const float* lp = cur + WSZ;
-    // one tap: all CK/2 channel pairs' operands are fetched first (TM + TN ds_read_b32 per pair), then the MFMAs
-    auto do_tap = [&](int tap, int toff) {
-      constexpr int NCP = CK / 2 / KG;               // channel pairs of this wave group
-      float a[NCP][TM], bv[NCP][TN];
+    // software pipeline over taps: tap t+1's operands (TM + TN ds_read_b32 per channel pair) are in flight while
+    // tap t's MFMAs run; sched_barrier keeps hipcc from sinking the reads next to their uses
+    constexpr int NCP = CK / 2 / KG;                 // channel pairs of this wave group
+    float a[NCP][TM], bv[NCP][TN], an[NCP][TM], bn[NCP][TN];
+    auto load_tap = [&](int tap, int toff, float (&aa)[NCP][TM], float (&bb)[NCP][TN]) {
 #pragma unroll
       for (int cp = 0; cp < NCP; ++cp) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[cp][i] = lw[tap * CK * MB + (kg * NCP + cp) * 2 * MB + i * 32];
+        for (int i = 0; i < TM; ++i) aa[cp][i] = lw[tap * CK * MB + (kg * NCP + cp) * 2 * MB + i * 32];
 #pragma unroll
-        for (int f = 0; f < TN; ++f) bv[cp][f] = lp[lane_base[f] + toff + (kg * NCP + cp) * 2 * g.CSl];
+        for (int f = 0; f < TN; ++f) bb[cp][f] = lp[lane_base[f] + toff + (kg * NCP + cp) * 2 * g.CSl];
       }
+    };
+    auto mfma_tap = [&](const float (&aa)[NCP][TM], const float (&bb)[NCP][TN]) {
 #pragma unroll
       for (int cp = 0; cp < NCP; ++cp)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int f = 0; f < TN; ++f)
-            acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp][i], bv[cp][f], acc[i][f], 0, 0, 0);
+            acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[cp][i], bb[cp][f], acc[i][f], 0, 0, 0);
     };
     if constexpr (NT > 0) {
+      load_tap(0, toffs[0], a, bv);
 #pragma unroll
-      for (int tap = 0; tap < NT; ++tap) do_tap(tap, toffs[tap]);
+      for (int tap = 0; tap < NT; tap += 2) {
+        if (tap + 1 < NT) load_tap(tap + 1, toffs[tap + 1 < NT ? tap + 1 : 0], an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tap(a, bv);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap + 1 < NT) {
+          if (tap + 2 < NT) load_tap(tap + 2, toffs[tap + 2 < NT ? tap + 2 : 0], a, bv);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_tap(an, bn);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     } else {
-      for (int tap = 0; tap < g.ntaps; ++tap) do_tap(tap, g.tap_off[tap]);
+      const int nt = g.ntaps;
+      if (nt > 0) load_tap(0, g.tap_off[0], a, bv);
+      for (int tap = 0; tap < nt; tap += 2) {
+        if (tap + 1 < nt) load_tap(tap + 1, g.tap_off[tap + 1], an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tap(a, bv);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap + 1 < nt) {
+          if (tap + 2 < nt) load_tap(tap + 2, g.tap_off[tap + 2], a, bv);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_tap(an, bn);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
   }
 
