@@ -708,6 +708,8 @@ extern "C" int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const flo
   g.src = dy; g.src_y = y_act; g.wp = wp_d; g.bias = nullptr; g.res = dx_add; g.dst = dx; g.act_epi = P2I_ACT_NONE; g.act_pro = y_act ? act : P2I_ACT_NONE;
   g.mask_y = mask_y; g.mask_act = mask_y ? mask_act : P2I_ACT_NONE;
   P2I_REQUIRE(!(mask_y && y_act), "dgrad: use either the act'(y) prologue or the epilogue mask");
+  if (d->Cin == 1 && !y_act && d->kt * d->kh * d->kw * d->Cout * 4 <= 64 * 1024)
+    return c1_dgrad(d, dy, wp_d, dx_add, mask_y, mask_act, dx, (hipStream_t)stream);
   g.B = d->B; g.Ck = d->Cout; g.Cm = d->Cin; g.CmPad = (d->Cin + 31) / 32 * 32;
   g.wp_bytes = 4u * (unsigned)(d->kt * d->kh * d->kw) * g.Ck * g.CmPad;
   g.sT = d->To; g.sH = d->Ho; g.sW = d->Wo; g.dT = d->Ti; g.dH = d->Hi; g.dW = d->Wi;

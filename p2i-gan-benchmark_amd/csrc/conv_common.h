@@ -70,4 +70,9 @@ static inline int check_desc(const p2i_conv_desc* d) {
 }
 
 
+// single-input-channel special cases (conv_c1.hip)
+int c1_dgrad(const p2i_conv_desc* d, const float* dy, const float* wp_d, const float* add, const float* mask_y, int mask_act,
+             float* dx, hipStream_t s);
+int c1_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* dbias, hipStream_t s);
+
 }  // namespace p2i

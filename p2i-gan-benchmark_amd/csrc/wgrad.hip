@@ -331,6 +331,7 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
   if (int e = check_desc(d)) return e;
   P2I_REQUIRE(x && dy && dwp, "null pointer");
   hipStream_t s = (hipStream_t)stream;
+  if (d->Cin == 1 && d->Cout <= 32 && d->kt * d->kh * d->kw <= 32 && !y_act) return c1_wgrad(d, x, dy, dwp, dbias, s);
   WgradGeom g{};
   g.x = x; g.dy = dy; g.y_act = y_act; g.dwp = dwp; g.act = act;
   g.B = d->B; g.Cx = d->Cin; g.Co = d->Cout; g.CoPad = (d->Cout + 31) / 32 * 32;

@@ -85,6 +85,11 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     gin = gout * {"none": 1.0, "relu": (y > 0).float(), "leaky": torch.where(y > 0, 1.0, 0.2), "tanh": 1 - y * y}[act]
     dx2 = ops.conv_dgrad(spec, gin.detach().to(dev).contiguous(), wp_d, tuple(x.shape), add=addt.to(dev), mask_y=mk.to(dev), mask_act=ops.ACT_RELU)
     assert rel_err(dx2.cpu().numpy(), ((x.grad + addt) * (mk > 0)).numpy()) < TOL_OP
+    # prologue-free weight gradient on the pre-masked gradient (what the model code uses)
+    dwp2, db2 = ops.conv_wgrad(spec, xg, gin.detach().to(dev).contiguous(), want_bias=has_bias)
+    assert rel_err(ops.weight_unpack_grad(dwp2, w.detach().to(dev)).cpu().numpy(), w.grad.numpy()) < TOL_WGRAD
+    if has_bias:
+        assert rel_err(db2.cpu().numpy(), bias.grad.numpy()) < TOL_WGRAD
     dwp, db = ops.conv_wgrad(spec, xg, gout.to(dev), y_act, act_code, want_bias=has_bias)
     dw = ops.weight_unpack_grad(dwp, w.detach().to(dev))
     assert rel_err(dw.cpu().numpy(), w.grad.numpy()) < TOL_WGRAD
