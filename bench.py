@@ -123,7 +123,7 @@ def main():
             eng.train_step(frames, masked, masks)
         summ = ops.PROFILE.summary()
         ops.PROFILE = None
-        gemm = {k: v for k, v in summ.items() if k.startswith("patch_gemm_kernel<")}
+        gemm = {k: v for k, v in summ.items() if k.startswith("patch_gemm_dma_kernel<")}
         dom = max(gemm, key=lambda k: gemm[k]["seconds"])
         d = gemm[dom]
         ach = d["flops"] / d["seconds"] / 1e12

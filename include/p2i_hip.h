@@ -69,9 +69,10 @@ int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const float* y_act, 
                    float* dx, void* stream);
 int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, const float* y_act,
                    int act, float* dwp, float* dbias, void* stream);
-/* tile plan {MB, NPIX, WAVES_M, CK} of the calling thread's most recent fwd/dgrad launch (names the
- * patch_gemm_kernel<MB,NPIX,WAVES_M,CK> instance for profiling; bench.py's roofline uses it) */
-int p2i_conv_last_plan(int* out4);
+/* tile plan {MB, NPIX, WAVES_M, CK, NT, KG} of the calling thread's most recent fwd/dgrad launch: names the
+ * patch_gemm_dma_kernel<MB,NPIX,WAVES_M,CK,NT,KG> instance (NT = -1: the prologue kernel
+ * patch_gemm_kernel<MB,NPIX,WAVES_M,CK>) so that bench.py's roofline can be matched to rocprofv3 rows */
+int p2i_conv_last_plan(int* out6);
 
 /* ------------------------------------------------------------------ weight preparation
  * p2i_doconv_fold_fwd: DoW = einsum('ims,ois->oim', D + D_diag, W.reshape(O/g, I, 9)) with the

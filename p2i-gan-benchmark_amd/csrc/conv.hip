@@ -459,7 +459,7 @@ static int launch_patch_dma_nt(const PatchGeom& g, dim3 grid, size_t lds, hipStr
 }
 template <int MB, int NPIX, int WM, int CK, int KG>
 static int launch_patch_dma(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
-  if constexpr (CK <= 8) {
+  if constexpr (CK <= 8 || KG == 2) {
     if (g.ntaps == 9) return launch_patch_dma_nt<MB, NPIX, WM, CK, 9, KG>(g, grid, lds, s);
   }
   if (g.ntaps == 1) return launch_patch_dma_nt<MB, NPIX, WM, CK, 1, KG>(g, grid, lds, s);
@@ -528,7 +528,7 @@ struct ClassSpec {
   int dt[MAX_TAPS], dh[MAX_TAPS], dw[MAX_TAPS];
 };
 
-static thread_local int g_last_plan[4] = {0, 0, 0, 0};
+static thread_local int g_last_plan[6] = {0, 0, 0, 0, 0, 0};
 
 static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
   g.nT = cs.nT; g.nH = cs.nH; g.nW = cs.nW;
@@ -570,7 +570,8 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
       t.rpc = jb * t.eth;
       t.CSl = t.rpc * t.eW;
       t.CS = t.CSl;
-      for (int CKc = (cs.ntaps <= 4 ? 16 : 8); CKc >= 2; CKc >>= 1) {
+      static const int force_ck16 = getenv("P2I_CONV_CK16") ? atoi(getenv("P2I_CONV_CK16")) : 0;
+      for (int CKc = ((cs.ntaps <= 4 || ((force_ck16 || g.Ck >= 256) && cs.ntaps == 9 && MBc <= 64)) ? 16 : 8); CKc >= 2; CKc >>= 1) {
         if (g.Ck >= CKc ? (g.Ck % CKc != 0) : (CKc != 2 && g.Ck * 2 <= CKc)) continue;
         if (CKc == 2 && !(MBc == 64 && NP == 128) && !(MBc == 32)) continue;      // instantiated CK=2 tiles
         if ((CKc == 4 || CKc == 16) && MBc == 128 && NP == 128) continue;
@@ -608,8 +609,10 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
       const long long nb = (long long)best_grid.x * best_grid.y;
       const int acc_regs = (c.MB / 32) * (c.NPIX / 32) / 4 * 16;
       const size_t red_bytes = (size_t)4 * acc_regs * 64 * 4;
-      const int KG = (nb <= 320 && c.CK >= 8 && c.MB <= 64 && red_bytes <= best_lds) ? 2 : 1;
+      const int KG = ((nb <= 320 || (c.CK == 16 && cs.ntaps == 9)) && c.CK >= 8 && c.MB <= 64 && red_bytes <= best_lds) ? 2 : 1;
       g_last_plan[0] = c.MB; g_last_plan[1] = c.NPIX; g_last_plan[2] = c.WM; g_last_plan[3] = c.CK;
+      g_last_plan[4] = (cs.ntaps == 9 && (c.CK <= 8 || KG == 2)) ? 9 : (cs.ntaps == 1 ? 1 : ((cs.ntaps == 27 && c.CK <= 4 && KG == 1) ? 27 : 0));
+      g_last_plan[5] = KG;
       return dispatch_patch_dma(c, KG, bg, best_grid, best_lds, s);
     }
   }
@@ -659,7 +662,7 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
     g.ntt = ceil_div(cs.nT, jt); g.nth = ceil_div(cs.nH, jh); g.ntw = ceil_div(cs.nW, jw);
     const int ntb = ceil_div(g.B, jb);
     dim3 grid((unsigned)(ntb * g.ntt * g.nth * g.ntw), (unsigned)ceil_div(g.Cm, c.MB));
-    g_last_plan[0] = c.MB; g_last_plan[1] = c.NPIX; g_last_plan[2] = c.WM; g_last_plan[3] = c.CK;
+    g_last_plan[0] = c.MB; g_last_plan[1] = c.NPIX; g_last_plan[2] = c.WM; g_last_plan[3] = c.CK; g_last_plan[4] = -1; g_last_plan[5] = 0;
     return dispatch_patch(c, g, grid, lds, s);
   }
   set_error("conv tile selection failed");
@@ -670,9 +673,9 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
 
 using namespace p2i;
 
-extern "C" int p2i_conv_last_plan(int* out4) {
-  if (!out4) return P2I_EINVAL;
-  for (int i = 0; i < 4; ++i) out4[i] = g_last_plan[i];
+extern "C" int p2i_conv_last_plan(int* out6) {
+  if (!out6) return P2I_EINVAL;
+  for (int i = 0; i < 6; ++i) out6[i] = g_last_plan[i];
   return P2I_OK;
 }
 

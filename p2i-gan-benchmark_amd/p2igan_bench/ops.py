@@ -70,12 +70,17 @@ def _prof_end(e0, kind, spec, desc, stride1):
     e1.record()
     flops = 2.0 * desc.B * desc.Cout * desc.Cin * spec.ntaps * desc.To * desc.Ho * desc.Wo
     if kind == "wgrad":
-        key = "wgrad_kernel<64>"
+        key = "wgrad_dma_kernel<64, ...> / wgrad_kernel<64>"
     else:
         import ctypes
-        plan = (ctypes.c_int * 4)()
+        plan = (ctypes.c_int * 6)()
         _hip.load().p2i_conv_last_plan(plan)
-        key = "patch_gemm_kernel<%d,%d,%d,%d>" % tuple(plan) if stride1 else "patch_gemm_kernel(strided classes)"
+        if not stride1:
+            key = "patch_gemm_dma_kernel(strided dgrad: one launch per parity class)"
+        elif plan[4] < 0:
+            key = "patch_gemm_kernel<%d, %d, %d, %d>" % tuple(plan[:4])
+        else:
+            key = "patch_gemm_dma_kernel<%d, %d, %d, %d, %d, %d>" % tuple(plan)
     PROFILE.records.append((key, flops, e0, e1))
 
 

@@ -21,7 +21,7 @@ def run(C,S,kind):
     e1.record(); torch.cuda.synchronize()
     us=e0.elapsed_time(e1)*1e3/n
     import ctypes
-    plan=(ctypes.c_int*4)(); ops._hip.load().p2i_conv_last_plan(plan)
+    plan=(ctypes.c_int*6)(); ops._hip.load().p2i_conv_last_plan(plan)
     print(f"B={B} C={C} S={S} {kind}: {us:.1f} us  {fl/us/1e6:.1f} TF plan={tuple(plan)}",flush=True)
 for (C,S) in [(64,128),(128,64),(256,32),(512,16)]:
     for kind in ["fwd","dgrad","wgrad"]:
