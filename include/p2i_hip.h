@@ -73,6 +73,9 @@ int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, cons
  * patch_gemm_dma_kernel<MB,NPIX,WAVES_M,CK,NT,KG> instance (NT = -1: the prologue kernel
  * patch_gemm_kernel<MB,NPIX,WAVES_M,CK>) so that bench.py's roofline can be matched to rocprofv3 rows */
 int p2i_conv_last_plan(int* out6);
+/* same for the most recent p2i_conv_wgrad: {kind (0 wgrad_kernel<64>, 1 wgrad_dma_kernel<64,NTAP,Y4,CB>, 2 c1_wgrad_kernel),
+ * NTAP, Y4, CB} */
+int p2i_wgrad_last_plan(int* out4);
 
 /* ------------------------------------------------------------------ weight preparation
  * p2i_doconv_fold_fwd: DoW = einsum('ims,ois->oim', D + D_diag, W.reshape(O/g, I, 9)) with the
@@ -164,6 +167,8 @@ int p2i_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
 
 /* small helpers on the same stream */
 int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stream);        /* y += a*x */
+/* out = dy * act'(y) for a saved post-activation tensor y (may alias dy): ReLU / LeakyReLU(0.2) / tanh backward */
+int p2i_act_bwd(const float* dy, const float* y, int act, float* out, int64_t n, void* stream);
 int p2i_bias_grad(const float* dy, const float* y_act, int act, float* db, int B, int C, int64_t inner, void* stream);
 
 #ifdef __cplusplus

@@ -311,6 +311,17 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, const float* __re
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) atomicAdd(db + c, acc);
 }
+// out = dy * act'(y) (y = saved post-activation tensor); float4 streams
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, float* out, int64_t n4, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 g = reinterpret_cast<const float4*>(dy)[i], v = reinterpret_cast<const float4*>(y)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(act_grad(g.x, v.x, act), act_grad(g.y, v.y, act), act_grad(g.z, v.z, act), act_grad(g.w, v.w, act));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    out[i] = act_grad(dy[i], y[i], act);
+  }
+}
 __global__ void axpy_kernel(float* y, const float* __restrict__ x, float a, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += a * x[i];
 }
@@ -411,6 +422,11 @@ extern "C" int p2i_bias_grad(const float* dy, const float* y_act, int act, float
   if (chunks > 64) chunks = 64;
   if (chunks < 1) chunks = 1;
   hipLaunchKernelGGL(bias_grad_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dy, y_act, act, db, B, C, inner);
+  return launch_status();
+}
+extern "C" int p2i_act_bwd(const float* dy, const float* y, int act, float* out, int64_t n, void* stream) {
+  P2I_REQUIRE(dy && y && out && n > 0, "null pointer");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dy, y, act, out, n / 4, n);
   return launch_status();
 }
 extern "C" int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stream) {

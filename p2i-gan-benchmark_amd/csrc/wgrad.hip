@@ -311,6 +311,38 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
       }
     }
   }
+  // combine the KS pixel-range partial sums inside the workgroup (through LDS, 4 taps at a time) so that only
+  // one wave per (c tile, o tile) issues the global float atomics: they run at ~1.3 TB/s chip-wide and would
+  // otherwise cost as much as a third of a small launch
+  constexpr int TCH = 4;
+  const int wtile = wm * 2 + wn;                           // (c tile, o tile) of this wave: 0 .. 2*CT-1
+#pragma unroll
+  for (int tc = 0; tc < NTAP; tc += TCH) {
+    __syncthreads();
+    if (kh > 0) {
+      float* dst = smem + (((kh - 1) * 2 * CT + wtile) * TCH * 16 << 6) + lane;
+#pragma unroll
+      for (int t = 0; t < TCH; ++t)
+        if (tc + t < NTAP) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[(t * 16 + r) << 6] = acc[tc + t][r];
+        }
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int g2 = 0; g2 < KS - 1; ++g2) {
+        const float* src = smem + ((g2 * 2 * CT + wtile) * TCH * 16 << 6) + lane;
+#pragma unroll
+        for (int t = 0; t < TCH; ++t)
+          if (tc + t < NTAP) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tc + t][r] += src[(t * 16 + r) << 6];
+          }
+      }
+    }
+  }
+  if (kh != 0) return;
 #pragma unroll
   for (int t = 0; t < NTAP; ++t) {
     const int o = o0 + wn * 32 + l31;
@@ -326,12 +358,24 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
 
 using namespace p2i;
 
+static thread_local int g_wgrad_plan[4] = {0, 0, 0, 0};   // {kind 0 prologue kernel / 1 dma / 2 single-channel, NTAP, Y4, CB}
+
+extern "C" int p2i_wgrad_last_plan(int* out4) {
+  if (!out4) return P2I_EINVAL;
+  for (int i = 0; i < 4; ++i) out4[i] = g_wgrad_plan[i];
+  return P2I_OK;
+}
+
 extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, const float* y_act,
                               int act, float* dwp, float* dbias, void* stream) {
   if (int e = check_desc(d)) return e;
   P2I_REQUIRE(x && dy && dwp, "null pointer");
   hipStream_t s = (hipStream_t)stream;
-  if (d->Cin == 1 && d->Cout <= 32 && d->kt * d->kh * d->kw <= 32 && !y_act) return c1_wgrad(d, x, dy, dwp, dbias, s);
+  if (d->Cin == 1 && d->Cout <= 32 && d->kt * d->kh * d->kw <= 32 && !y_act) {
+    g_wgrad_plan[0] = 2; g_wgrad_plan[1] = d->kt * d->kh * d->kw; g_wgrad_plan[2] = 0; g_wgrad_plan[3] = 1;
+    return c1_wgrad(d, x, dy, dwp, dbias, s);
+  }
+  g_wgrad_plan[0] = 0; g_wgrad_plan[1] = d->kh * d->kw; g_wgrad_plan[2] = 0; g_wgrad_plan[3] = 64;
   WgradGeom g{};
   g.x = x; g.dy = dy; g.y_act = y_act; g.dwp = dwp; g.act = act;
   g.B = d->B; g.Cx = d->Cin; g.Co = d->Cout; g.CoPad = (d->Cout + 31) / 32 * 32;
@@ -391,6 +435,7 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
       g.rowblk = (CBh * g.eWq + 63) & ~63;
       g.XSZ = jb * g.eH * g.rowblk;
       lds2 = sizeof(float) * 2 * ((size_t)((g.XSZ + 3) & ~3) + (size_t)((64 * PPh + 255) / 256) * 256);
+      { const size_t red = sizeof(float) * 3 * 4 * 16 * 64 * 2; if (lds2 < red) lds2 = red; }   // k-split combine scratch
       if (lds2 <= 160 * 1024 || CBh == 32) break;
       CBh = 32;
     }
@@ -407,6 +452,7 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
       else kern = g.tpg == 9 ? (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 32> : (wk_t)wgrad_dma_kernel<NPIX, 9, false, 32>)
                              : (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 1, true, 32> : (wk_t)wgrad_dma_kernel<NPIX, 1, false, 32>);
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      g_wgrad_plan[0] = 1; g_wgrad_plan[1] = g.tpg; g_wgrad_plan[2] = y4 ? 1 : 0; g_wgrad_plan[3] = CBh;
       const int ncb = ceil_div(d->Cin, CBh);
       int ns = 256 / (ncb * nco);        // LDS admits one (8-wave) block per CU
       if (ns < 1) ns = 1;

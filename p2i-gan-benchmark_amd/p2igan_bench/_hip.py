@@ -32,6 +32,7 @@ SIGNATURES = {
     "p2i_conv_dgrad": [_D, _P, _P, _I, _P, _P, _P, _I, _P, _P],
     "p2i_conv_wgrad": [_D, _P, _P, _P, _I, _P, _P, _P],
     "p2i_conv_last_plan": [C.POINTER(C.c_int)],
+    "p2i_wgrad_last_plan": [C.POINTER(C.c_int)],
     "p2i_doconv_fold_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "p2i_doconv_fold_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "p2i_weight_pack": [_P, _I, _I, _I, _P, _P, _P, _P],
@@ -51,6 +52,7 @@ SIGNATURES = {
     "p2i_gan_loss": [_P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P],
     "p2i_adam": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P],
     "p2i_axpy": [_P, _P, _F, _L, _P],
+    "p2i_act_bwd": [_P, _P, _I, _P, _L, _P],
     "p2i_bias_grad": [_P, _P, _I, _P, _I, _I, _L, _P],
 }
 

@@ -220,9 +220,10 @@ class _GeneratorFn(torch.autograd.Function):
         # ---- ConvsOut (grouped 1x1, dense-lowered) + tanh
         spec_out = _spec2d(BASE_CH, t, 1)
         cout = _doconv_of(net.ConvsOut[0])
-        dwp, _ = ops.conv_wgrad(spec_out, S["h0"], dz, S["z"], ACT_TANH, arena=arena)
+        dz = ops.act_bwd(dz, S["z"], ACT_TANH)                      # * (1 - z^2): prologue-free kernels below
+        dwp, _ = ops.conv_wgrad(spec_out, S["h0"], dz, arena=arena)
         grads[id(cout.W)], _ = ops.doconv_fold_bwd(dwp, *cout.tensors(), t, BASE_CH, 4, 1)
-        dh = ops.conv_dgrad(spec_out, dz, S["wp_out_d"], tuple(S["h0"].shape), S["z"], ACT_TANH)
+        dh = ops.conv_dgrad(spec_out, dz, S["wp_out_d"], tuple(S["h0"].shape))
 
         def eblock_bwd(lvl, dh):
             ch = BASE_CH << lvl
@@ -243,10 +244,11 @@ class _GeneratorFn(torch.autograd.Function):
             hin, u, r, wpd = S["up"][i]
             cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
             spec = _spec2d(cin_, cout_, 1)
-            dwp, db = ops.conv_wgrad(spec, u, dr, r, ACT_RELU, want_bias=True, arena=arena)
+            dr = ops.act_bwd(dr, r, ACT_RELU)                       # * relu'(r) once, for wgrad and dgrad
+            dwp, db = ops.conv_wgrad(spec, u, dr, want_bias=True, arena=arena)
             grads[id(up.proj.weight)] = ops.weight_unpack_grad(dwp, up.proj.weight.reshape(cout_, cin_, 1)).reshape(up.proj.weight.shape)
             grads[id(up.proj.bias)] = db
-            du = ops.conv_dgrad(spec, dr, wpd, tuple(u.shape), r, ACT_RELU)
+            du = ops.conv_dgrad(spec, dr, wpd, tuple(u.shape))
             dx, dpos = ops.upmod_bwd(hin, up.pos, du)
             grads[id(up.pos)] = dpos
             return dx

@@ -70,7 +70,11 @@ def _prof_end(e0, kind, spec, desc, stride1):
     e1.record()
     flops = 2.0 * desc.B * desc.Cout * desc.Cin * spec.ntaps * desc.To * desc.Ho * desc.Wo
     if kind == "wgrad":
-        key = "wgrad_dma_kernel<64, ...> / wgrad_kernel<64>"
+        import ctypes
+        wp = (ctypes.c_int * 4)()
+        _hip.load().p2i_wgrad_last_plan(wp)
+        key = {0: "wgrad_kernel<64>", 2: "c1_wgrad_kernel<32>"}.get(wp[0]) or \
+            "wgrad_dma_kernel<64, %d, %s, %d>%s" % (wp[1], "true" if wp[2] else "false", wp[3], "" if spec.k[0] == 1 else " (x%d kt slices)" % spec.k[0])
     else:
         import ctypes
         plan = (ctypes.c_int * 6)()
@@ -484,6 +488,17 @@ def axpy_(y, x, a=1.0):
     _chk(y, x)
     _hip.check(lib.p2i_axpy(_ptr(y), _ptr(x), float(a), y.numel(), _stream()), "p2i_axpy")
     return y
+
+
+def act_bwd(dy, y, act):
+    """dy * act'(y) for the saved post-activation tensor y."""
+    lib = _hip.load()
+    if dy.shape != y.shape:
+        raise RuntimeError("act_bwd: shape mismatch")
+    out = torch.empty_like(dy)
+    _chk(dy, y)
+    _hip.check(lib.p2i_act_bwd(_ptr(dy), _ptr(y), act, _ptr(out), dy.numel(), _stream()), "p2i_act_bwd")
+    return out
 
 
 def bias_grad(dy, y_act=None, act=ACT_NONE):
