@@ -19,6 +19,14 @@
 
 namespace p2i {
 
+// per-class fields of a merged multi-class launch (strided dgrad: blockIdx.z = input-parity class)
+struct ClassGeom {
+  int nT, nH, nW, pT, pH, pW, bT, bH, bW, ntaps;
+  short tap_w[MAX_TAPS];
+  int tap_off[MAX_TAPS];
+};
+constexpr int MAX_CLASSES = 8;
+
 struct PatchGeom {
   const float* src;
   const float* src_y;   // dgrad: saved activation output for act'(y) (may be null)
@@ -52,6 +60,8 @@ struct PatchGeom {
   int PT;               // patch dwords per chunk = CK * CSl
   unsigned src_bytes, wp_bytes;
   unsigned mg_csl, mg_ew;
+  int nclass;           // > 1: fields below override nT..ntaps / tap tables per blockIdx.z
+  ClassGeom cls[MAX_CLASSES];
 };
 
 template <int MB, int NPIX, int WAVES_M, int CK>
@@ -210,6 +220,15 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
   constexpr int TM = MB / (32 * WAVES_M);
   constexpr int TN = NPIX / (32 * WAVES_N);
   constexpr int V = MB / 4;                          // float4 per weight row
+  // class-local geometry (merged strided-dgrad launches pick theirs by blockIdx.z; scalar loads from kernarg)
+  const bool multi = g.nclass > 1;
+  const ClassGeom& cg = g.cls[multi ? blockIdx.z : 0];
+  const int c_nT = multi ? cg.nT : g.nT, c_nH = multi ? cg.nH : g.nH, c_nW = multi ? cg.nW : g.nW;
+  const int c_pT = multi ? cg.pT : g.pT, c_pH = multi ? cg.pH : g.pH, c_pW = multi ? cg.pW : g.pW;
+  const int c_bT = multi ? cg.bT : g.bT, c_bH = multi ? cg.bH : g.bH, c_bW = multi ? cg.bW : g.bW;
+  const int c_ntaps = multi ? cg.ntaps : g.ntaps;
+  const short* c_tap_w = multi ? cg.tap_w : g.tap_w;
+  const int* c_tap_off = multi ? cg.tap_off : g.tap_off;
   const int nwrows = g.ntaps * CK;
   const int WSZ = ((nwrows * V + 63) & ~63) * 4;     // weight floats per chunk (padded to whole wave-instructions)
   const int PTp = (g.PT + 63) & ~63;                 // patch dwords per chunk, padded to a wave-instruction
@@ -233,14 +252,14 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
   const int o0 = blockIdx.y * MB;
   const int JWm = (1 << g.ljw) - 1, JHm = (1 << g.ljh) - 1, JTm = (1 << g.ljt) - 1;
   const int sHW = g.sH * g.sW;
-  const int src_t0 = j0t * g.mT + g.bT, src_h0 = j0h * g.mH + g.bH, src_w0 = j0w * g.mW + g.bW;
+  const int src_t0 = j0t * g.mT + c_bT, src_h0 = j0h * g.mH + c_bH, src_w0 = j0w * g.mW + c_bW;
 
   // ---- offset tables (bytes; 0xFFFFFFFC = out of range -> DMA writes 0)
   for (int r = tid; r < wtab_sz; r += NTH) {
     int off = -4;
     if (r < nwrows) {
       const int tap = r / CK, c = r - tap * CK;
-      if (c < g.Ck && o0 < g.CmPad) off = ((g.tap_w[tap] * g.Ck + c) * g.CmPad + o0) * 4;
+      if (tap < c_ntaps && c < g.Ck && o0 < g.CmPad) off = ((c_tap_w[tap] * g.Ck + c) * g.CmPad + o0) * 4;
     }
     wtab[r] = off;
   }
@@ -315,7 +334,7 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
   int toffs[NT > 0 ? NT : 1];
   if constexpr (NT > 0) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) toffs[t] = g.tap_off[t];
+    for (int t = 0; t < NT; ++t) toffs[t] = c_tap_off[t];
   }
   const int nchunks = (g.Ck + CK - 1) / CK;
   issue(0, buf0_off);
@@ -364,15 +383,15 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
         }
       }
     } else {
-      const int nt = g.ntaps;
-      if (nt > 0) load_tap(0, g.tap_off[0], a, bv);
+      const int nt = c_ntaps;
+      if (nt > 0) load_tap(0, c_tap_off[0], a, bv);
       for (int tap = 0; tap < nt; tap += 2) {
-        if (tap + 1 < nt) load_tap(tap + 1, g.tap_off[tap + 1], an, bn);
+        if (tap + 1 < nt) load_tap(tap + 1, c_tap_off[tap + 1], an, bn);
         __builtin_amdgcn_sched_barrier(0);
         mfma_tap(a, bv);
         __builtin_amdgcn_sched_barrier(0);
         if (tap + 1 < nt) {
-          if (tap + 2 < nt) load_tap(tap + 2, g.tap_off[tap + 2], a, bv);
+          if (tap + 2 < nt) load_tap(tap + 2, c_tap_off[tap + 2], a, bv);
           __builtin_amdgcn_sched_barrier(0);
           mfma_tap(an, bn);
           __builtin_amdgcn_sched_barrier(0);
@@ -409,8 +428,8 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
     const int gh = j0h + ((pix >> g.ljw) & JHm);
     const int gt = j0t + ((pix >> (g.ljw + g.ljh)) & JTm);
     const int gb = j0b + (pix >> (g.ljw + g.ljh + g.ljt));
-    const bool pv = gb < g.B && gt < g.nT && gh < g.nH && gw < g.nW;
-    const int sp = (gt * g.oT + g.pT) * dHW + (gh * g.oH + g.pH) * g.dW + gw * g.oW + g.pW;
+    const bool pv = gb < g.B && gt < c_nT && gh < c_nH && gw < c_nW;
+    const int sp = (gt * g.oT + c_pT) * dHW + (gh * g.oH + c_pH) * g.dW + gw * g.oW + c_pW;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -459,6 +478,7 @@ static int launch_patch_dma_nt(const PatchGeom& g, dim3 grid, size_t lds, hipStr
 }
 template <int MB, int NPIX, int WM, int CK, int KG>
 static int launch_patch_dma(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
+  if (g.nclass > 1) return launch_patch_dma_nt<MB, NPIX, WM, CK, 0, KG>(g, grid, lds, s);
   if constexpr (CK <= 8 || KG == 2) {
     if (g.ntaps == 9) return launch_patch_dma_nt<MB, NPIX, WM, CK, 9, KG>(g, grid, lds, s);
   }
@@ -530,12 +550,132 @@ struct ClassSpec {
 
 static thread_local int g_last_plan[6] = {0, 0, 0, 0, 0, 0};
 
+static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s);
+
+// One launch for `ncls` classes sharing source/dest tensors and multipliers (strided dgrad: blockIdx.z = class).
+// Returns 1 if the merged DMA launch is not possible (caller falls back to one launch per class).
+static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, hipStream_t s) {
+  if (g.src_y != nullptr || ncls > MAX_CLASSES) return 1;
+  const ClassSpec& c0s = css[0];
+  g.mT = c0s.mT; g.mH = c0s.mH; g.mW = c0s.mW;
+  g.oT = c0s.oT; g.oH = c0s.oH; g.oW = c0s.oW;
+  int lo[MAX_CLASSES][3], rng[3] = {0, 0, 0}, mx[3] = {0, 0, 0}, max_taps = 0;
+  long long total_pix = 0;
+  for (int q = 0; q < ncls; ++q) {
+    const ClassSpec& cs = css[q];
+    int hi[3] = {0, 0, 0};
+    lo[q][0] = lo[q][1] = lo[q][2] = 0;
+    for (int i = 0; i < cs.ntaps; ++i) {
+      const int d[3] = {cs.dt[i], cs.dh[i], cs.dw[i]};
+      for (int k = 0; k < 3; ++k) {
+        if (i == 0 || d[k] < lo[q][k]) lo[q][k] = d[k];
+        if (i == 0 || d[k] > hi[k]) hi[k] = d[k];
+      }
+    }
+    for (int k = 0; k < 3; ++k) if (hi[k] - lo[q][k] > rng[k]) rng[k] = hi[k] - lo[q][k];
+    if (cs.nT > mx[0]) mx[0] = cs.nT;
+    if (cs.nH > mx[1]) mx[1] = cs.nH;
+    if (cs.nW > mx[2]) mx[2] = cs.nW;
+    if (cs.ntaps > max_taps) max_taps = cs.ntaps;
+    total_pix += (long long)g.B * (cs.nT > 0 ? cs.nT : 0) * (cs.nH > 0 ? cs.nH : 0) * (cs.nW > 0 ? cs.nW : 0);
+  }
+  if (mx[0] <= 0 || mx[1] <= 0 || mx[2] <= 0) return P2I_OK;
+  if (max_taps == 0) max_taps = 1;                       // a class without taps still has to write zeros
+  g.ntaps = max_taps;
+  static const int cand[5][3] = {{128, 256, 2}, {64, 256, 1}, {128, 128, 2}, {64, 128, 2}, {32, 128, 1}};
+  int best = -1, best_ck = 0;
+  long long best_score = -1;
+  PatchGeom bg = g;
+  size_t best_lds = 0;
+  dim3 best_grid;
+  for (int ci = 0; ci < 5; ++ci) {
+    const int MBc = cand[ci][0], NP = cand[ci][1];
+    if (MBc > 32 && g.Cm <= MBc / 2) continue;            // more than half of the m-tile would be padding
+    int jb, jt, jh, jw;
+    pick_tile_dims(NP, g.B, mx[0], mx[1], mx[2], jb, jt, jh, jw);
+    PatchGeom t = g;
+    t.ljb = ilog2(jb); t.ljt = ilog2(jt); t.ljh = ilog2(jh); t.ljw = ilog2(jw);
+    t.eT = (jt - 1) * g.mT + rng[0] + 1;
+    t.eH = (jh - 1) * g.mH + rng[1] + 1;
+    t.eW = (jw - 1) * g.mW + rng[2] + 1;
+    t.eWp = t.eW;
+    t.eth = t.eT * t.eH;
+    t.rpc = jb * t.eth;
+    t.CSl = t.rpc * t.eW;
+    t.CS = t.CSl;
+    static const int force_ck16 = getenv("P2I_CONV_CK16") ? atoi(getenv("P2I_CONV_CK16")) : 0;
+    for (int CKc = ((max_taps <= 4 || ((force_ck16 || g.Ck >= 256) && max_taps == 9 && MBc <= 64)) ? 16 : 8); CKc >= 2; CKc >>= 1) {
+      if (g.Ck >= CKc ? (g.Ck % CKc != 0) : (CKc != 2 && g.Ck * 2 <= CKc)) continue;
+      if (CKc == 2 && !(MBc == 64 && NP == 128) && !(MBc == 32)) continue;      // instantiated CK=2 tiles
+      if ((CKc == 4 || CKc == 16) && MBc == 128 && NP == 128) continue;
+      const int PT = CKc * t.CSl;
+      if (PT >= 65536 || t.CSl >= 65536) continue;
+      const int PTp = (PT + 63) & ~63;
+      const int nwrows = max_taps * CKc;
+      const size_t WSZ = (size_t)((nwrows * (MBc / 4) + 63) & ~63) * 4;
+      const size_t lds = sizeof(float) * (((nwrows + 63) & ~63) + (size_t)PTp + 2 * (WSZ + PTp));
+      if (lds > 160 * 1024) continue;
+      const long long nb = (long long)ceil_div(g.Cm, MBc) * ((total_pix + NP - 1) / NP);
+      // score: filling the chip first, then MFMA work per staged byte (tile area), then deeper chunks
+      long long score = (nb >= 256 ? 1000000000ll : nb * 1000000ll) + (long long)MBc * NP * 10 + CKc + (lds <= 80 * 1024 ? 5 : 0);
+      if (score > best_score) {
+        best_score = score; best = ci; best_ck = CKc; best_lds = lds;
+        bg = t; bg.PT = PT;
+        bg.ntt = ceil_div(mx[0], jt); bg.nth = ceil_div(mx[1], jh); bg.ntw = ceil_div(mx[2], jw);
+        best_grid = dim3((unsigned)(ceil_div(g.B, jb) * bg.ntt * bg.nth * bg.ntw), (unsigned)ceil_div(g.Cm, MBc), (unsigned)ncls);
+      }
+      break;   // largest feasible CK for this tile
+    }
+  }
+  const unsigned long long sbytes = 4ull * g.B * g.Ck * g.sT * g.sH * g.sW;
+  if (best < 0 || sbytes >= 0xF0000000ull) return 1;
+  TileCfg c{cand[best][0], cand[best][1], cand[best][2], best_ck};
+  bg.mg_csl = magic_u16(bg.CSl); bg.mg_ew = magic_u16(bg.eW);
+  bg.mg_rpc = magic_u16(bg.rpc); bg.mg_eth = magic_u16(bg.eth); bg.mg_eh = magic_u16(bg.eH);
+  bg.src_bytes = (unsigned)sbytes;
+  bg.wp_bytes = g.wp_bytes;
+  bg.nclass = ncls;
+  for (int q = 0; q < ncls; ++q) {
+    const ClassSpec& cs = css[q];
+    ClassGeom& cgm = bg.cls[q];
+    cgm.nT = cs.nT; cgm.nH = cs.nH; cgm.nW = cs.nW;
+    cgm.pT = cs.pT; cgm.pH = cs.pH; cgm.pW = cs.pW;
+    cgm.bT = lo[q][0]; cgm.bH = lo[q][1]; cgm.bW = lo[q][2];
+    cgm.ntaps = cs.ntaps;
+    for (int i = 0; i < cs.ntaps; ++i) {
+      cgm.tap_w[i] = cs.tw[i];
+      cgm.tap_off[i] = ((cs.dt[i] - lo[q][0]) * bg.eH + (cs.dh[i] - lo[q][1])) * bg.eW + (cs.dw[i] - lo[q][2]);
+    }
+  }
+  // single class: the top-level fields are the class
+  bg.nT = css[0].nT; bg.nH = css[0].nH; bg.nW = css[0].nW;
+  bg.pT = css[0].pT; bg.pH = css[0].pH; bg.pW = css[0].pW;
+  bg.bT = lo[0][0]; bg.bH = lo[0][1]; bg.bW = lo[0][2];
+  for (int i = 0; i < css[0].ntaps; ++i) { bg.tap_w[i] = bg.cls[0].tap_w[i]; bg.tap_off[i] = bg.cls[0].tap_off[i]; }
+  if (ncls == 1) bg.ntaps = css[0].ntaps;
+  // ~1 workgroup per CU or fewer: 8-wave workgroups with intra-block split-K (small accumulator tiles only)
+  const long long nb = (long long)best_grid.x * best_grid.y * best_grid.z;
+  const int acc_regs = (c.MB / 32) * (c.NPIX / 32) / 4 * 16;
+  const size_t red_bytes = (size_t)4 * acc_regs * 64 * 4;
+  const int KG = ((nb <= 320 || (c.CK == 16 && max_taps == 9)) && c.CK >= 8 && c.MB <= 64 && red_bytes <= best_lds) ? 2 : 1;
+  g_last_plan[0] = c.MB; g_last_plan[1] = c.NPIX; g_last_plan[2] = c.WM; g_last_plan[3] = c.CK;
+  g_last_plan[4] = ncls > 1 ? 0 : ((max_taps == 9 && (c.CK <= 8 || KG == 2)) ? 9 : (max_taps == 1 ? 1 : ((max_taps == 27 && c.CK <= 4 && KG == 1) ? 27 : 0)));
+  g_last_plan[5] = KG;
+  return dispatch_patch_dma(c, KG, bg, best_grid, best_lds, s);
+}
+
 static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
+  if (cs.nT <= 0 || cs.nH <= 0 || cs.nW <= 0) return P2I_OK;
+  // ---- DMA-pipelined path (no act'(y) prologue)
+  {
+    const int rc = run_patch_gemm_classes(g, &cs, 1, s);
+    if (rc != 1) return rc;
+  }
   g.nT = cs.nT; g.nH = cs.nH; g.nW = cs.nW;
   g.mT = cs.mT; g.mH = cs.mH; g.mW = cs.mW;
   g.oT = cs.oT; g.oH = cs.oH; g.oW = cs.oW; g.pT = cs.pT; g.pH = cs.pH; g.pW = cs.pW;
   g.ntaps = cs.ntaps;
-  if (cs.nT <= 0 || cs.nH <= 0 || cs.nW <= 0) return P2I_OK;
+  g.nclass = 1;
   int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   for (int i = 0; i < cs.ntaps; ++i) {
     const int d[3] = {cs.dt[i], cs.dh[i], cs.dw[i]};
@@ -545,77 +685,6 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
     }
   }
   g.bT = lo[0]; g.bH = lo[1]; g.bW = lo[2];
-
-  // ---- DMA-pipelined path (no act'(y) prologue): pick the largest tile that still fills the chip
-  if (g.src_y == nullptr) {
-    static const int cand[5][3] = {{128, 256, 2}, {64, 256, 1}, {128, 128, 2}, {64, 128, 2}, {32, 128, 1}};
-    const long long total_pix = (long long)g.B * cs.nT * cs.nH * cs.nW;
-    int best = -1, best_ck = 0;
-    long long best_score = -1;
-    PatchGeom bg = g;
-    size_t best_lds = 0;
-    dim3 best_grid;
-    for (int ci = 0; ci < 5; ++ci) {
-      const int MBc = cand[ci][0], NP = cand[ci][1];
-      if (MBc > 32 && g.Cm <= MBc / 2) continue;            // more than half of the m-tile would be padding
-      int jb, jt, jh, jw;
-      pick_tile_dims(NP, g.B, cs.nT, cs.nH, cs.nW, jb, jt, jh, jw);
-      PatchGeom t = g;
-      t.ljb = ilog2(jb); t.ljt = ilog2(jt); t.ljh = ilog2(jh); t.ljw = ilog2(jw);
-      t.eT = (jt - 1) * cs.mT + (hi[0] - lo[0]) + 1;
-      t.eH = (jh - 1) * cs.mH + (hi[1] - lo[1]) + 1;
-      t.eW = (jw - 1) * cs.mW + (hi[2] - lo[2]) + 1;
-      t.eWp = t.eW;
-      t.eth = t.eT * t.eH;
-      t.rpc = jb * t.eth;
-      t.CSl = t.rpc * t.eW;
-      t.CS = t.CSl;
-      static const int force_ck16 = getenv("P2I_CONV_CK16") ? atoi(getenv("P2I_CONV_CK16")) : 0;
-      for (int CKc = ((cs.ntaps <= 4 || ((force_ck16 || g.Ck >= 256) && cs.ntaps == 9 && MBc <= 64)) ? 16 : 8); CKc >= 2; CKc >>= 1) {
-        if (g.Ck >= CKc ? (g.Ck % CKc != 0) : (CKc != 2 && g.Ck * 2 <= CKc)) continue;
-        if (CKc == 2 && !(MBc == 64 && NP == 128) && !(MBc == 32)) continue;      // instantiated CK=2 tiles
-        if ((CKc == 4 || CKc == 16) && MBc == 128 && NP == 128) continue;
-        const int PT = CKc * t.CSl;
-        if (PT >= 65536 || t.CSl >= 65536) continue;
-        const int PTp = (PT + 63) & ~63;
-        const int nwrows = cs.ntaps * CKc;
-        const size_t WSZ = (size_t)((nwrows * (MBc / 4) + 63) & ~63) * 4;
-        const size_t lds = sizeof(float) * (((nwrows + 63) & ~63) + (size_t)PTp + 2 * (WSZ + PTp));
-        if (lds > 160 * 1024) continue;
-        const long long nb = (long long)ceil_div(g.Cm, MBc) * ((total_pix + NP - 1) / NP);
-        // score: filling the chip first, then MFMA work per staged byte (tile area), then deeper chunks
-        long long score = (nb >= 256 ? 1000000000ll : nb * 1000000ll) + (long long)MBc * NP * 10 + CKc + (lds <= 80 * 1024 ? 5 : 0);
-        if (score > best_score) {
-          best_score = score; best = ci; best_ck = CKc; best_lds = lds;
-          bg = t; bg.PT = PT;
-          bg.ntt = ceil_div(cs.nT, jt); bg.nth = ceil_div(cs.nH, jh); bg.ntw = ceil_div(cs.nW, jw);
-          best_grid = dim3((unsigned)(ceil_div(g.B, jb) * bg.ntt * bg.nth * bg.ntw), (unsigned)ceil_div(g.Cm, MBc));
-        }
-        break;   // largest feasible CK for this tile
-      }
-    }
-    const unsigned long long sbytes = 4ull * g.B * g.Ck * g.sT * g.sH * g.sW;
-    if (best >= 0 && sbytes < 0xF0000000ull) {
-      TileCfg c{cand[best][0], cand[best][1], cand[best][2], best_ck};
-      bg.mg_csl = magic_u16(bg.CSl); bg.mg_ew = magic_u16(bg.eW);
-      bg.mg_rpc = magic_u16(bg.rpc); bg.mg_eth = magic_u16(bg.eth); bg.mg_eh = magic_u16(bg.eH);
-      bg.src_bytes = (unsigned)sbytes;
-      bg.wp_bytes = g.wp_bytes;
-      for (int i = 0; i < cs.ntaps; ++i) {
-        bg.tap_w[i] = cs.tw[i];
-        bg.tap_off[i] = ((cs.dt[i] - lo[0]) * bg.eH + (cs.dh[i] - lo[1])) * bg.eW + (cs.dw[i] - lo[2]);
-      }
-      // ~1 workgroup per CU or fewer: 8-wave workgroups with intra-block split-K (small accumulator tiles only)
-      const long long nb = (long long)best_grid.x * best_grid.y;
-      const int acc_regs = (c.MB / 32) * (c.NPIX / 32) / 4 * 16;
-      const size_t red_bytes = (size_t)4 * acc_regs * 64 * 4;
-      const int KG = ((nb <= 320 || (c.CK == 16 && cs.ntaps == 9)) && c.CK >= 8 && c.MB <= 64 && red_bytes <= best_lds) ? 2 : 1;
-      g_last_plan[0] = c.MB; g_last_plan[1] = c.NPIX; g_last_plan[2] = c.WM; g_last_plan[3] = c.CK;
-      g_last_plan[4] = (cs.ntaps == 9 && (c.CK <= 8 || KG == 2)) ? 9 : (cs.ntaps == 1 ? 1 : ((cs.ntaps == 27 && c.CK <= 4 && KG == 1) ? 27 : 0));
-      g_last_plan[5] = KG;
-      return dispatch_patch_dma(c, KG, bg, best_grid, best_lds, s);
-    }
-  }
 
   // ---- tile configuration
   TileCfg c;
@@ -716,7 +785,10 @@ extern "C" int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const flo
   g.B = d->B; g.Ck = d->Cout; g.Cm = d->Cin; g.CmPad = (d->Cin + 31) / 32 * 32;
   g.wp_bytes = 4u * (unsigned)(d->kt * d->kh * d->kw) * g.Ck * g.CmPad;
   g.sT = d->To; g.sH = d->Ho; g.sW = d->Wo; g.dT = d->Ti; g.dH = d->Hi; g.dW = d->Wi;
-  // one launch per parity class of the input index modulo the stride
+  // input-parity classes modulo the stride: merged into ONE launch (blockIdx.z = class) when possible
+  ClassSpec css[MAX_CLASSES];
+  int ncls = 0;
+  const bool mergeable = d->st * d->sh * d->sw <= MAX_CLASSES;
   for (int ct = 0; ct < d->st; ++ct)
     for (int chh = 0; chh < d->sh; ++chh)
       for (int cw = 0; cw < d->sw; ++cw) {
@@ -734,15 +806,23 @@ extern "C" int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const flo
             for (int c = 0; c < d->kw; ++c) {
               if ((cw + d->pw - c) % d->sw) continue;
               cs.tw[n] = (short)((a * d->kh + b) * d->kw + c);
-              // floor division is exact here (divisible), C++ division of negatives truncates: fine when divisible
+              // exact division (divisible by construction)
               cs.dt[n] = (ct + d->pt - a) / d->st; cs.dh[n] = (chh + d->ph - b) / d->sh; cs.dw[n] = (cw + d->pw - c) / d->sw;
               ++n;
             }
           }
         }
         cs.ntaps = n;
-        if (int e = run_patch_gemm(g, cs, (hipStream_t)stream)) return e;
+        if (mergeable) css[ncls++] = cs;
+        else if (int e = run_patch_gemm(g, cs, (hipStream_t)stream)) return e;
       }
+  if (mergeable) {
+    const int rc = ncls > 1 ? run_patch_gemm_classes(g, css, ncls, (hipStream_t)stream) : 1;
+    if (rc == 1) {
+      for (int q = 0; q < ncls; ++q)
+        if (int e = run_patch_gemm(g, css[q], (hipStream_t)stream)) return e;
+    } else if (rc != P2I_OK) return rc;
+  }
   return P2I_OK;
 }
 
