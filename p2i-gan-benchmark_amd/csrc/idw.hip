@@ -43,7 +43,7 @@ __global__ void idw_count_kernel(const float* __restrict__ mask, int32_t* frame_
 __global__ __launch_bounds__(256) void idw_compact_kernel(const float* __restrict__ mask, const int32_t* __restrict__ frame_count,
                                                          const float* __restrict__ gx, const float* __restrict__ gy,
                                                          const float* __restrict__ gz, int32_t* pt_pos, int32_t* pt_count,
-                                                         float* pt_xyzn, int T, int H, int W) {
+                                                         int32_t* row_start, float* pt_xyzn, int T, int H, int W) {
   __shared__ int wsum[4];
   __shared__ int s_base;
   const int bt = blockIdx.x, b = bt / T, t = bt % T, HW = H * W, Q = T * HW;
@@ -67,6 +67,8 @@ __global__ __launch_bounds__(256) void idw_compact_kernel(const float* __restric
     __syncthreads();
     int woff = 0, tot = 0;
     for (int k = 0; k < 4; ++k) { if (k < wave) woff += wsum[k]; tot += wsum[k]; }
+    // row_start[b][t][y] = index (within the sample's point list) of the first point of frame t in a row >= y
+    if (i < HW && (i % W) == 0) row_start[(size_t)bt * (H + 1) + i / W] = base + woff + rank;
     if (on) {
       const int j = base + woff + rank;
       const int y = i / W, x = i - y * W;
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(256) void idw_compact_kernel(const float* __restric
     base += tot;
     __syncthreads();
   }
+  if (threadIdx.x == 0) row_start[(size_t)bt * (H + 1) + H] = base;
   (void)gx; (void)gy; (void)gz;
 }
 
@@ -86,14 +89,16 @@ __global__ __launch_bounds__(256) void idw_compact_kernel(const float* __restric
 __global__ __launch_bounds__(256) void idw_knn_kernel(const float* __restrict__ vals, const float* __restrict__ gx,
                                                      const float* __restrict__ gy, const float* __restrict__ gz,
                                                      const int32_t* __restrict__ pt_pos, const int32_t* __restrict__ pt_count,
-                                                     const float4* __restrict__ pt_xyzn, float* out, int32_t* sel_idx,
+                                                     const int32_t* __restrict__ row_start, const float4* __restrict__ pt_xyzn, float* out, int32_t* sel_idx,
                                                      float* sel_w, int T, int H, int W, float tau) {
   const int b = blockIdx.y, HW = H * W, Q = T * HW;
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= Q) return;
+  const int q_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = q_raw < Q;                       // inactive lanes shadow the last voxel: wave reductions below
+  const int q = active ? q_raw : Q - 1;                // need every lane to hold defined values
   const int N = pt_count[b];
   const size_t qo = (size_t)b * Q + q;
   if (N < 4) {       // N == 0: zeros (layer.py:330-332); 0 < N < 4: reference raises in topk
+    if (!active) return;
     out[qo] = 0.f;
     if (sel_idx) {
       *reinterpret_cast<int4*>(sel_idx + qo * 4) = make_int4(0, 0, 0, 0);
@@ -129,13 +134,38 @@ __global__ __launch_bounds__(256) void idw_knn_kernel(const float* __restrict__ 
   }
   // fast reject: r2 = fl(fl(r*r)*(1+2^-20)) > r^2 exactly, so c2 >= r2 implies sqrt_rn(c2) >= r (no insert,
   // as std::partial_sort's strict comparison demands); below r2 the exact d-space test decides.
-  for (int j = 4; j < N; ++j) {
-    const float c2 = dist2(pts[j]);
-    if (c2 < r2) {
-      const float dc = sqrtf(fmaxf(c2, 0.f));
-      if (dc < h0d) {
-        HEAP4_REPLACE_ROOT(dc, j);
-        r2 = h0d * h0d * 1.000001f + 1e-30f;
+  //
+  // Exact pruning.  Points are scanned in index order (frame-major, then row-major) exactly like the reference,
+  // but whole frames / row ranges that provably cannot beat the CURRENT root are skipped: a skipped point has
+  // |dz| or |dy| (hence its computed distance, up to the 2e-6 slack that covers the fp32 cancellation of the
+  // |a|^2+|b|^2-2ab chain) above the root at its turn, so std::partial_sort would not have inserted it either
+  // and the heap evolves identically.  Bounds are wave-uniform (max root / row span over the lanes).
+  const int* rs = row_start + (size_t)b * T * (H + 1);
+  const float inv_h = 1.f / (float)max(H - 1, 1);
+  for (int f = 0; f < T; ++f) {
+    const int fs = rs[f * (H + 1)], fe = rs[f * (H + 1) + H];
+    if (fe <= 4 || fs == fe) continue;                 // points 0..3 seeded the heap
+    const float r2w = wave_max(r2) + 2e-6f;
+    const float dzf = fabsf(qz - gz[f]) - 1e-6f;       // gz[f] == f/(T-1) as the points carry it (to 1 ulp)
+    const float dz2 = dzf > 0.f ? dzf * dzf : 0.f;
+    if (dz2 > r2w) continue;                           // the whole frame is farther than every lane's root
+    const float ry = sqrtf(r2w - dz2);
+    int kk = (int)(ry * (float)max(H - 1, 1)) + 2;     // rows that can hold a point within ry (+ slack)
+    if (kk > H) kk = H;
+    const int ymin = -(int)wave_max((float)(-y)), ymax = (int)wave_max((float)y);
+    const int ya = max(0, ymin - kk), yb = min(H, ymax + kk + 1);
+    (void)inv_h;
+    int lo = rs[f * (H + 1) + ya];
+    const int hi = rs[f * (H + 1) + yb];
+    if (lo < 4) lo = 4;
+    for (int j = lo; j < hi; ++j) {
+      const float c2 = dist2(pts[j]);
+      if (c2 < r2) {
+        const float dc = sqrtf(fmaxf(c2, 0.f));
+        if (dc < h0d) {
+          HEAP4_REPLACE_ROOT(dc, j);
+          r2 = h0d * h0d * 1.000001f + 1e-30f;
+        }
       }
     }
   }
@@ -160,6 +190,7 @@ __global__ __launch_bounds__(256) void idw_knn_kernel(const float* __restrict__ 
   w0 = __fdiv_rn(w0, ws); w1 = __fdiv_rn(w1, ws); w2 = __fdiv_rn(w2, ws); w3 = __fdiv_rn(w3, ws);
   const int32_t* pp = pt_pos + (size_t)b * Q;
   const float* vb = vals + (size_t)b * Q;
+  if (!active) return;
   const float v0 = vb[pp[h0i]], v1 = vb[pp[h1i]], v2 = vb[pp[h2i]], v3 = vb[pp[h3i]];
   out[qo] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(v0, w0), __fmul_rn(v1, w1)), __fmul_rn(v2, w2)), __fmul_rn(v3, w3));
   if (sel_idx) {
@@ -190,17 +221,17 @@ using namespace p2i;
 
 extern "C" int p2i_idw_fwd(const float* vals_src, const float* mask, const float* grid_x, const float* grid_y,
                            const float* grid_z, float* out, int32_t* pt_pos, int32_t* pt_count, int32_t* frame_count,
-                           float* pt_xyzn, int32_t* sel_idx, float* sel_w, int B, int T, int H, int W, float tau, void* stream) {
-  P2I_REQUIRE(vals_src && mask && grid_x && grid_y && grid_z && out && pt_pos && pt_count && frame_count && pt_xyzn,
+                           int32_t* row_start, float* pt_xyzn, int32_t* sel_idx, float* sel_w, int B, int T, int H, int W, float tau, void* stream) {
+  P2I_REQUIRE(vals_src && mask && grid_x && grid_y && grid_z && out && pt_pos && pt_count && frame_count && row_start && pt_xyzn,
               "null pointer");
   P2I_REQUIRE((sel_idx == nullptr) == (sel_w == nullptr), "sel_idx and sel_w go together");
   P2I_REQUIRE((long long)B * T * H * W < (1ll << 29), "IDW problem too large");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(idw_count_kernel, dim3(B * T), dim3(256), 0, s, mask, frame_count, H * W);
   hipLaunchKernelGGL(idw_compact_kernel, dim3(B * T), dim3(256), 0, s, mask, frame_count, grid_x, grid_y, grid_z, pt_pos, pt_count,
-                     pt_xyzn, T, H, W);
+                     row_start, pt_xyzn, T, H, W);
   hipLaunchKernelGGL(idw_knn_kernel, dim3(ceil_div(T * H * W, 256), B), dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos,
-                     pt_count, reinterpret_cast<const float4*>(pt_xyzn), out, sel_idx, sel_w, T, H, W, tau);
+                     pt_count, row_start, reinterpret_cast<const float4*>(pt_xyzn), out, sel_idx, sel_w, T, H, W, tau);
   return launch_status();
 }
 

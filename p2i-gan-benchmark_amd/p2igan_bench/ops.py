@@ -338,12 +338,13 @@ def idw_fwd(vals_src, mask, tau=0.05, save=True):
     pt_pos = torch.empty(B * Q, device=dev, dtype=torch.int32)
     pt_count = torch.empty(B, device=dev, dtype=torch.int32)
     frame_count = torch.empty(B * T, device=dev, dtype=torch.int32)
+    row_start = torch.empty(B * T * (H + 1), device=dev, dtype=torch.int32)
     pt_xyzn = torch.empty(B * Q * 4, device=dev, dtype=torch.float32)
     sel_idx = torch.empty(B * Q * 4, device=dev, dtype=torch.int32) if save else None
     sel_w = torch.empty(B * Q * 4, device=dev, dtype=torch.float32) if save else None
     _chk(vals_src, mask)
     _hip.check(lib.p2i_idw_fwd(_ptr(vals_src), _ptr(mask), _ptr(gx), _ptr(gy), _ptr(gz), _ptr(out), _ptr(pt_pos), _ptr(pt_count),
-                               _ptr(frame_count), _ptr(pt_xyzn), _ptr(sel_idx), _ptr(sel_w), B, T, H, W, float(tau), _stream()),
+                               _ptr(frame_count), _ptr(row_start), _ptr(pt_xyzn), _ptr(sel_idx), _ptr(sel_w), B, T, H, W, float(tau), _stream()),
                "p2i_idw_fwd")
     return out, (pt_pos, pt_count, sel_idx, sel_w)
 
