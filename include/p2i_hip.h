@@ -123,15 +123,15 @@ int p2i_attn_bwd(const float* x, const float* w0, const float* b0, const float* 
  *   pt_pos  int32 [B*Q]  flat (t,y,x) index of each point;  pt_count int32 [B] ; frame_count int32[B*T]
  *   row_start int32 [B*T*(H+1)]  first point of frame t in a row >= y (lets the scan skip, exactly, the
  *             frames / rows that cannot beat the current 4th-nearest distance)
- *   sel_idx int32 [B*Q*4], sel_w float [B*Q*4]  (saved for backward)
+ *   sel_idx int32 [B*Q*4] (indices into the point list), sel_w float [B*Q*4]  (saved for backward)
  * Empty mask => zeros (layer.py:330-332). 0 < N < 4 is an error in the reference (topk k>N);
  * here the output is NaN-free but unspecified and p2i_idw_status reports it. */
 int p2i_idw_fwd(const float* vals_src, const float* mask, const float* grid_x, const float* grid_y,
                 const float* grid_z, float* out, int32_t* pt_pos, int32_t* pt_count, int32_t* frame_count,
                 int32_t* row_start, float* pt_xyzn, int32_t* sel_idx, float* sel_w, int B, int T, int H, int W, float tau,
                 void* stream);
-int p2i_idw_bwd(const float* dout, const int32_t* pt_pos, const int32_t* sel_idx, const float* sel_w,
-                float* dvals_src, int B, int T, int H, int W, void* stream);
+int p2i_idw_bwd(const float* dout, const int32_t* pt_pos, const int32_t* pt_count, const int32_t* sel_idx,
+                const float* sel_w, float* dvals_src, int B, int T, int H, int W, void* stream);
 
 /* DownsampleDuplicateChannels (layer.py:205-214): 2x2 max-pool then duplicate every channel. */
 int p2i_pooldup_fwd(const float* x, float* y, int B, int C, int H, int W, void* stream);

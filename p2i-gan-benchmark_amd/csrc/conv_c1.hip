@@ -20,24 +20,20 @@ __global__ __launch_bounds__(256) void c1_dgrad_kernel(const p2i_conv_desc d, co
     const int wi = idx % d.Wi, hi = (idx / d.Wi) % d.Hi, ti = (idx / HWi) % d.Ti;
     const int b = idx / ((size_t)HWi * d.Ti);
     float acc = 0.f;
-    for (int a = 0; a < d.kt; ++a) {
-      const int tn = ti + d.pt - a;
-      if (tn < 0 || tn % d.st) continue;
-      const int to = tn / d.st;
-      if (to >= d.To) continue;
-      for (int bb = 0; bb < d.kh; ++bb) {
-        const int hn = hi + d.ph - bb;
-        if (hn < 0 || hn % d.sh) continue;
-        const int ho = hn / d.sh;
-        if (ho >= d.Ho) continue;
-        for (int c = 0; c < d.kw; ++c) {
-          const int wn = wi + d.pw - c;
-          if (wn < 0 || wn % d.sw) continue;
-          const int wo = wn / d.sw;
-          if (wo >= d.Wo) continue;
+    // only the taps congruent to (i + pad) modulo the stride reach an output position: step through those
+    for (int a = (ti + d.pt) % d.st; a < d.kt; a += d.st) {
+      const int to = (ti + d.pt - a) / d.st;
+      if (ti + d.pt - a < 0 || to >= d.To) continue;
+      for (int bb = (hi + d.ph) % d.sh; bb < d.kh; bb += d.sh) {
+        const int ho = (hi + d.ph - bb) / d.sh;
+        if (hi + d.ph - bb < 0 || ho >= d.Ho) continue;
+        for (int c = (wi + d.pw) % d.sw; c < d.kw; c += d.sw) {
+          const int wo = (wi + d.pw - c) / d.sw;
+          if (wi + d.pw - c < 0 || wo >= d.Wo) continue;
           const float* w = sw + ((a * d.kh + bb) * d.kw + c) * d.Cout;
           const float* g = dy + (((size_t)b * d.Cout) * d.To + to) * HWo + ho * d.Wo + wo;
           const size_t cs = (size_t)d.To * HWo;
+#pragma unroll 8
           for (int o = 0; o < d.Cout; ++o) acc += w[o] * g[o * cs];
         }
       }

@@ -38,6 +38,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   for (int t = 0; t < T; ++t) out[((size_t)b * T + t) * HW + p] = h[t];
 }
 
+template <int T>
+__device__ __forceinline__ void attn_bwd_pixel(const float* __restrict__ x, const float* __restrict__ dout, float (&sw)[2][T * T + T],
+                                               float (&sg)[2][T * T + T], int b, int p, int HW);
+
 // parameter gradients only (the block's input is data).  Pixels whose dout is all zero (every
 // non-gauge pixel: the IDW scatter touches gauge voxels only) are skipped.
 template <int T>
@@ -46,10 +50,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ b1, const float* __restrict__ dout,
                                                        float* dw0, float* db0, float* dw1, float* db1, int B, int HW) {
   __shared__ float sw[2][T * T + T];
+  __shared__ float sg[2][T * T + T];
   for (int i = threadIdx.x; i < T * T; i += blockDim.x) { sw[0][i] = w0[i]; sw[1][i] = w1[i]; }
   for (int i = threadIdx.x; i < T; i += blockDim.x) { sw[0][T * T + i] = b0[i]; sw[1][T * T + i] = b1[i]; }
+  for (int i = threadIdx.x; i < 2 * (T * T + T); i += blockDim.x) (&sg[0][0])[i] = 0.f;
   __syncthreads();
   const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  attn_bwd_pixel<T>(x, dout, sw, sg, b, p, HW);
+  __syncthreads();
+  for (int i = threadIdx.x; i < T * T + T; i += blockDim.x) {
+    const float v0 = sg[0][i], v1 = sg[1][i];
+    if (v0 != 0.f) atomicAdd((i < T * T ? dw0 + i : db0 + (i - T * T)), v0);
+    if (v1 != 0.f) atomicAdd((i < T * T ? dw1 + i : db1 + (i - T * T)), v1);
+  }
+}
+
+template <int T>
+__device__ __forceinline__ void attn_bwd_pixel(const float* __restrict__ x, const float* __restrict__ dout, float (&sw)[2][T * T + T],
+                                               float (&sg)[2][T * T + T], int b, int p, int HW) {
   if (p >= HW) return;
   float go[T];
   bool any = false;
@@ -92,17 +110,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const float da1 = a1[i] > 0.f ? dh1[i] : 0.f;
     dg1[i] = da1 * h0[i];
   }
+  // accumulate in LDS (few gauge pixels per block), then one global atomic per parameter per block
 #pragma unroll
   for (int i = 0; i < T; ++i) {
     if (dg2[i] != 0.f) {
-      atomicAdd(db1 + i, dg2[i]);
+      atomicAdd(&sg[1][T * T + i], dg2[i]);
 #pragma unroll
-      for (int j = 0; j < T; ++j) atomicAdd(dw1 + i * T + j, dg2[i] * h1[j]);
+      for (int j = 0; j < T; ++j) atomicAdd(&sg[1][i * T + j], dg2[i] * h1[j]);
     }
     if (dg1[i] != 0.f) {
-      atomicAdd(db0 + i, dg1[i]);
+      atomicAdd(&sg[0][T * T + i], dg1[i]);
 #pragma unroll
-      for (int j = 0; j < T; ++j) atomicAdd(dw0 + i * T + j, dg1[i] * h0[j]);
+      for (int j = 0; j < T; ++j) atomicAdd(&sg[0][i * T + j], dg1[i] * h0[j]);
     }
   }
 }

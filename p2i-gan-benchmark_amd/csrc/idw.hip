@@ -194,25 +194,50 @@ __global__ __launch_bounds__(256) void idw_knn_kernel(const float* __restrict__ 
   const float v0 = vb[pp[h0i]], v1 = vb[pp[h1i]], v2 = vb[pp[h2i]], v3 = vb[pp[h3i]];
   out[qo] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(v0, w0), __fmul_rn(v1, w1)), __fmul_rn(v2, w2)), __fmul_rn(v3, w3));
   if (sel_idx) {
-    *reinterpret_cast<int4*>(sel_idx + qo * 4) = make_int4(pp[h0i], pp[h1i], pp[h2i], pp[h3i]);
+    *reinterpret_cast<int4*>(sel_idx + qo * 4) = make_int4(h0i, h1i, h2i, h3i);      // POINT indices (pt_pos maps them to voxels)
     *reinterpret_cast<float4*>(sel_w + qo * 4) = make_float4(w0, w1, w2, w3);
   }
 }
 
-// backward: d vals[pos] += w * dout[q]   (values enter the output linearly; weights are data)
-__global__ void idw_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ sel_idx, const float* __restrict__ sel_w,
-                               float* dvals, int Q, size_t total) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+// backward: d vals[pt_pos[j]] += w * dout[q]   (values enter the output linearly; weights are data).
+// Every voxel adds into one of only N (gauge) addresses, so each block first accumulates in an LDS copy of the
+// point list (N <= IDW_LDS_PTS) and then issues one global atomic per touched point.
+constexpr int IDW_LDS_PTS = 8192;
+__global__ __launch_bounds__(256) void idw_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ pt_pos,
+                                                     const int32_t* __restrict__ pt_count, const int32_t* __restrict__ sel_idx,
+                                                     const float* __restrict__ sel_w, float* dvals, int Q, int chunk) {
+  __shared__ float accp[IDW_LDS_PTS];
+  const int b = blockIdx.y;
+  const int N = pt_count[b];
+  if (N < 4) return;
+  const bool use_lds = N <= IDW_LDS_PTS;
+  if (use_lds) {
+    for (int j = threadIdx.x; j < N; j += blockDim.x) accp[j] = 0.f;
+    __syncthreads();
+  }
+  const int32_t* pp = pt_pos + (size_t)b * Q;
+  float* dv = dvals + (size_t)b * Q;
+  const int q0 = blockIdx.x * chunk, q1 = min(Q, q0 + chunk);
+  for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
+    const size_t i = (size_t)b * Q + q;
     const float g = dout[i];
     if (g == 0.f) continue;
-    const size_t b = i / Q;
     const int4 id = *reinterpret_cast<const int4*>(sel_idx + i * 4);
     const float4 w = *reinterpret_cast<const float4*>(sel_w + i * 4);
-    float* dv = dvals + b * Q;
-    if (w.x != 0.f) atomicAdd(dv + id.x, g * w.x);
-    if (w.y != 0.f) atomicAdd(dv + id.y, g * w.y);
-    if (w.z != 0.f) atomicAdd(dv + id.z, g * w.z);
-    if (w.w != 0.f) atomicAdd(dv + id.w, g * w.w);
+    if (use_lds) {
+      atomicAdd(&accp[id.x], g * w.x); atomicAdd(&accp[id.y], g * w.y);
+      atomicAdd(&accp[id.z], g * w.z); atomicAdd(&accp[id.w], g * w.w);
+    } else {
+      atomicAdd(dv + pp[id.x], g * w.x); atomicAdd(dv + pp[id.y], g * w.y);
+      atomicAdd(dv + pp[id.z], g * w.z); atomicAdd(dv + pp[id.w], g * w.w);
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      const float v = accp[j];
+      if (v != 0.f) atomicAdd(dv + pp[j], v);
+    }
   }
 }
 
@@ -235,14 +260,14 @@ extern "C" int p2i_idw_fwd(const float* vals_src, const float* mask, const float
   return launch_status();
 }
 
-extern "C" int p2i_idw_bwd(const float* dout, const int32_t* pt_pos, const int32_t* sel_idx, const float* sel_w, float* dvals_src,
-                           int B, int T, int H, int W, void* stream) {
-  P2I_REQUIRE(dout && sel_idx && sel_w && dvals_src, "null pointer");
-  (void)pt_pos;
+extern "C" int p2i_idw_bwd(const float* dout, const int32_t* pt_pos, const int32_t* pt_count, const int32_t* sel_idx,
+                           const float* sel_w, float* dvals_src, int B, int T, int H, int W, void* stream) {
+  P2I_REQUIRE(dout && pt_pos && pt_count && sel_idx && sel_w && dvals_src, "null pointer");
   const int Q = T * H * W;
   const size_t total = (size_t)B * Q;
   (void)hipMemsetAsync(dvals_src, 0, sizeof(float) * total, (hipStream_t)stream);
-  hipLaunchKernelGGL(idw_bwd_kernel, dim3(min((size_t)8192, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, sel_idx,
-                     sel_w, dvals_src, Q, total);
+  const int chunk = 4096;
+  hipLaunchKernelGGL(idw_bwd_kernel, dim3(ceil_div(Q, chunk), B), dim3(256), 0, (hipStream_t)stream, dout, pt_pos, pt_count, sel_idx,
+                     sel_w, dvals_src, Q, chunk);
   return launch_status();
 }

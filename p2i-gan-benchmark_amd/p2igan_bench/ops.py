@@ -352,10 +352,11 @@ def idw_fwd(vals_src, mask, tau=0.05, save=True):
 def idw_bwd(dout, saved):
     lib = _hip.load()
     B, T, H, W = dout.shape
-    pt_pos, _, sel_idx, sel_w = saved
+    pt_pos, pt_count, sel_idx, sel_w = saved
     dvals = torch.empty_like(dout)
     _chk(dout)
-    _hip.check(lib.p2i_idw_bwd(_ptr(dout), _ptr(pt_pos), _ptr(sel_idx), _ptr(sel_w), _ptr(dvals), B, T, H, W, _stream()), "p2i_idw_bwd")
+    _hip.check(lib.p2i_idw_bwd(_ptr(dout), _ptr(pt_pos), _ptr(pt_count), _ptr(sel_idx), _ptr(sel_w), _ptr(dvals), B, T, H, W, _stream()),
+               "p2i_idw_bwd")
     return dvals
 
 
