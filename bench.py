@@ -114,15 +114,18 @@ def main():
 
     roofline = None
     extra = {}
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
         # instrumented pass (HIP events around every conv-engine launch on the launch stream); separate from
-        # the timed region above so that `value` is unperturbed
-        ops.PROFILE = ops.KernelProfile()
+        # the timed region above so that `value` is unperturbed.  Every rank steps (the step holds collectives);
+        # only rank 0 records.
+        if rank == 0:
+            ops.PROFILE = ops.KernelProfile()
         nprof = max(2, min(5, args.steps))
         for _ in range(nprof):
             eng.train_step(frames, masked, masks)
-        summ = ops.PROFILE.summary()
+        summ = ops.PROFILE.summary() if rank == 0 else None
         ops.PROFILE = None
+    if rank == 0 and not args.no_roofline:
         # dominant kernel = the conv-engine instance with the largest share of the step (single-kernel keys only)
         single = {k: v for k, v in summ.items() if k.startswith(("patch_gemm_dma_kernel<", "wgrad_dma_kernel<")) and "(" not in k}
         dom = max(single, key=lambda k: single[k]["seconds"])
