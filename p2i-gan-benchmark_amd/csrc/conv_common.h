@@ -13,7 +13,9 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 // LDS-DMA issued from inline asm: hipcc does not count these in vmcnt, so it neither drains them before the
 // next ds_read (it cannot prove the DMA's destination buffer differs from the one being read) nor before a
 // barrier -- the kernels below wait `s_waitcnt vmcnt(0)` themselves right before the barrier that hands the
-// buffer over.  M0 (LDS base of the wave-instruction) is saved/restored inside the same statement.
+// buffer over.  M0 (LDS base of the wave-instruction) is saved/restored inside the same statement; the leading
+// `s_nop 4` covers the v_readfirstlane -> VMEM-SGPR-operand hazard (soffset / descriptor words may be fresh),
+// which hipcc does not pad inside an asm string.
 __device__ __forceinline__ v4i32 make_rsrc(const void* p, unsigned bytes) {
   const unsigned long long a = (unsigned long long)p;
   v4i32 r;
@@ -31,14 +33,14 @@ __device__ __forceinline__ void dma_b32(const v4i32 rsrc, unsigned lds_addr, int
   const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr);
   const int so = __builtin_amdgcn_readfirstlane(soff);
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(la), "s"(rsrc), "s"(so) : "memory");
 }
 __device__ __forceinline__ void dma_b128(const v4i32 rsrc, unsigned lds_addr, int voff, int soff) {
   const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr);
   const int so = __builtin_amdgcn_readfirstlane(soff);
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(la), "s"(rsrc), "s"(so) : "memory");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
