@@ -19,50 +19,6 @@
 
 namespace p2i {
 
-// per-class fields of a merged multi-class launch (strided dgrad: blockIdx.z = input-parity class)
-struct ClassGeom {
-  int nT, nH, nW, pT, pH, pW, bT, bH, bW, ntaps;
-  short tap_w[MAX_TAPS];
-  int tap_off[MAX_TAPS];
-};
-constexpr int MAX_CLASSES = 8;
-
-struct PatchGeom {
-  const float* src;
-  const float* src_y;   // dgrad: saved activation output for act'(y) (may be null)
-  const float* wp;      // packed weights [tap][Ck][CmPad]
-  const float* bias;    // fwd epilogue (may be null)
-  const float* res;     // fwd epilogue residual, dest-shaped (may be null)
-  float* dst;
-  int act_epi;          // epilogue activation (forward)
-  int act_pro;          // prologue act'(y) code (dgrad)
-  int B, Ck, Cm, CmPad;
-  int sT, sH, sW;       // source tensor dims
-  int dT, dH, dW;       // dest tensor dims
-  int nT, nH, nW;       // dest-local extents
-  int mT, mH, mW;       // source multiplier S
-  int oT, oH, oW;       // dest index multiplier
-  int pT, pH, pW;       // dest index offset
-  int bT, bH, bW;       // min tap delta (patch origin = j0*S + b)
-  int eT, eH, eW, eWp;  // patch extents (eWp = row pitch)
-  int ljb, ljt, ljh, ljw;
-  int ntt, nth, ntw;    // tiles per dim (batch tiles = gridDim.x / (ntt*nth*ntw))
-  int ntaps;
-  int CS;               // patch channel stride (floats)
-  int rpc, eth;         // rows per channel = JB*eT*eH ; eT*eH
-  unsigned mg_rpc, mg_eth, mg_eh;
-  short tap_w[MAX_TAPS];
-  int tap_off[MAX_TAPS];
-  // ---- DMA-pipelined variant only
-  const float* mask_y;  // epilogue: dst *= act'(mask_y) (dest-shaped; the activation that PRODUCED dst's tensor)
-  int mask_act;
-  int CSl;              // linear (unpadded) patch channel stride = rpc * eW
-  int PT;               // patch dwords per chunk = CK * CSl
-  unsigned src_bytes, wp_bytes;
-  unsigned mg_csl, mg_ew;
-  int nclass;           // > 1: fields below override nT..ntaps / tap tables per blockIdx.z
-  ClassGeom cls[MAX_CLASSES];
-};
 
 template <int MB, int NPIX, int WAVES_M, int CK>
 __global__ __launch_bounds__(256) void patch_gemm_kernel(const PatchGeom g) {
@@ -538,15 +494,6 @@ static int dispatch_patch(const TileCfg& c, const PatchGeom& g, dim3 grid, size_
   return P2I_EINVAL;
 }
 
-// one (class of a) patch GEMM.  taps: arrays of weight-tap index and per-dim source delta.
-struct ClassSpec {
-  int nT, nH, nW;      // dest-local extents
-  int mT, mH, mW;      // source multiplier
-  int oT, oH, oW, pT, pH, pW;
-  int ntaps;
-  short tw[MAX_TAPS];
-  int dt[MAX_TAPS], dh[MAX_TAPS], dw[MAX_TAPS];
-};
 
 static thread_local int g_last_plan[6] = {0, 0, 0, 0, 0, 0};
 
@@ -556,6 +503,10 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s);
 // Returns 1 if the merged DMA launch is not possible (caller falls back to one launch per class).
 static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, hipStream_t s) {
   if (g.src_y != nullptr || ncls > MAX_CLASSES) return 1;
+  if (const X6Ctx& xc = x6_ctx(); xc.wb != nullptr) {        // inside a p2i_conv_*_x6 call: bf16-split engine first
+    const int rc = run_patch_gemm_x6(g, css, ncls, xc.wb, xc.ntaps_w, g_last_plan, s);
+    if (rc != 1) return rc;
+  }
   const ClassSpec& c0s = css[0];
   g.mT = c0s.mT; g.mH = c0s.mH; g.mW = c0s.mW;
   g.oT = c0s.oT; g.oH = c0s.oH; g.oW = c0s.oW;
@@ -826,3 +777,35 @@ extern "C" int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const flo
   return P2I_OK;
 }
 
+
+// ---- exact-fp32 convolution on the bf16 matrix pipe (conv_x6.hip).  `wsplit` is caller-owned scratch of
+// 3 * ntaps * K * pad32(M) bf16 (K = contraction channels, M = destination channels of the call) that receives the
+// 3-plane split of `wp`; layers the x6 engine does not cover run on the fp32-MFMA kernels above.
+namespace p2i { int x6_split_weights(const float* wp, uint16_t* wb, int ntaps, int Ck, int CmPad, hipStream_t s); }
+
+extern "C" int p2i_conv_fwd_x6(const p2i_conv_desc* d, const float* x, const float* wp, uint16_t* wsplit, const float* bias,
+                               const float* residual, float* y, int act, void* stream) {
+  if (int e = check_desc(d)) return e;
+  if (wsplit == nullptr || (d->Cin & 15) != 0) return p2i_conv_fwd(d, x, wp, bias, residual, y, act, stream);
+  P2I_REQUIRE(wp != nullptr, "null pointer");
+  const int nt = d->kt * d->kh * d->kw;
+  if (int e = x6_split_weights(wp, wsplit, nt, d->Cin, (d->Cout + 31) / 32 * 32, (hipStream_t)stream)) return e;
+  x6_ctx() = X6Ctx{wsplit, nt};
+  const int rc = p2i_conv_fwd(d, x, wp, bias, residual, y, act, stream);
+  x6_ctx() = X6Ctx{nullptr, 0};
+  return rc;
+}
+
+extern "C" int p2i_conv_dgrad_x6(const p2i_conv_desc* d, const float* dy, const float* wp_d, uint16_t* wsplit, const float* dx_add,
+                                 const float* mask_y, int mask_act, float* dx, void* stream) {
+  if (int e = check_desc(d)) return e;
+  if (wsplit == nullptr || (d->Cout & 15) != 0 || d->Cin == 1)
+    return p2i_conv_dgrad(d, dy, nullptr, P2I_ACT_NONE, wp_d, dx_add, mask_y, mask_act, dx, stream);
+  P2I_REQUIRE(wp_d != nullptr, "null pointer");
+  const int nt = d->kt * d->kh * d->kw;
+  if (int e = x6_split_weights(wp_d, wsplit, nt, d->Cout, (d->Cin + 31) / 32 * 32, (hipStream_t)stream)) return e;
+  x6_ctx() = X6Ctx{wsplit, nt};
+  const int rc = p2i_conv_dgrad(d, dy, nullptr, P2I_ACT_NONE, wp_d, dx_add, mask_y, mask_act, dx, stream);
+  x6_ctx() = X6Ctx{nullptr, 0};
+  return rc;
+}

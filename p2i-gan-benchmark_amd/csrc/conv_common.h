@@ -72,6 +72,73 @@ static inline int check_desc(const p2i_conv_desc* d) {
 }
 
 
+// per-class fields of a merged multi-class launch (strided dgrad: blockIdx.z = input-parity class)
+struct ClassGeom {
+  int nT, nH, nW, pT, pH, pW, bT, bH, bW, ntaps;
+  short tap_w[MAX_TAPS];
+  int tap_off[MAX_TAPS];
+};
+constexpr int MAX_CLASSES = 8;
+
+struct PatchGeom {
+  const float* src;
+  const float* src_y;   // dgrad: saved activation output for act'(y) (may be null)
+  const float* wp;      // packed weights [tap][Ck][CmPad]
+  const float* bias;    // fwd epilogue (may be null)
+  const float* res;     // fwd epilogue residual, dest-shaped (may be null)
+  float* dst;
+  int act_epi;          // epilogue activation (forward)
+  int act_pro;          // prologue act'(y) code (dgrad)
+  int B, Ck, Cm, CmPad;
+  int sT, sH, sW;       // source tensor dims
+  int dT, dH, dW;       // dest tensor dims
+  int nT, nH, nW;       // dest-local extents
+  int mT, mH, mW;       // source multiplier S
+  int oT, oH, oW;       // dest index multiplier
+  int pT, pH, pW;       // dest index offset
+  int bT, bH, bW;       // min tap delta (patch origin = j0*S + b)
+  int eT, eH, eW, eWp;  // patch extents (eWp = row pitch)
+  int ljb, ljt, ljh, ljw;
+  int ntt, nth, ntw;    // tiles per dim (batch tiles = gridDim.x / (ntt*nth*ntw))
+  int ntaps;
+  int CS;               // patch channel stride (floats)
+  int rpc, eth;         // rows per channel = JB*eT*eH ; eT*eH
+  unsigned mg_rpc, mg_eth, mg_eh;
+  short tap_w[MAX_TAPS];
+  int tap_off[MAX_TAPS];
+  // ---- DMA-pipelined variant only
+  const float* mask_y;  // epilogue: dst *= act'(mask_y) (dest-shaped; the activation that PRODUCED dst's tensor)
+  int mask_act;
+  int CSl;              // linear (unpadded) patch channel stride = rpc * eW
+  int PT;               // patch dwords per chunk = CK * CSl
+  unsigned src_bytes, wp_bytes;
+  unsigned mg_csl, mg_ew;
+  // ---- x6 (bf16-split) variant only
+  const uint16_t* wb;   // split weights [plane 3][ntaps_w][Ck/8][CmPad][8] bf16
+  unsigned wb_bytes;
+  int ntaps_w;          // taps of the full kernel (plane stride of wb)
+  int TG, NTP, R;       // taps per pipeline stage; padded tap count of the LDS weight-offset table; weight ring slots
+  int nclass;           // > 1: fields below override nT..ntaps / tap tables per blockIdx.z
+  ClassGeom cls[MAX_CLASSES];
+};
+
+// one (class of a) patch GEMM.  taps: arrays of weight-tap index and per-dim source delta.
+struct ClassSpec {
+  int nT, nH, nW;      // dest-local extents
+  int mT, mH, mW;      // source multiplier
+  int oT, oH, oW, pT, pH, pW;
+  int ntaps;
+  short tw[MAX_TAPS];
+  int dt[MAX_TAPS], dh[MAX_TAPS], dw[MAX_TAPS];
+};
+
+// exact-fp32 convolution on the bf16 matrix pipe (conv_x6.hip): set for the duration of a p2i_conv_*_x6 call,
+// points at the 3-plane bf16 split of the packed weights the call is about to use (nullptr: fp32 MFMA path)
+struct X6Ctx { const uint16_t* wb; int ntaps_w; };
+X6Ctx& x6_ctx();
+// returns 1 when no x6 instance fits (caller continues on the fp32-MFMA path)
+int run_patch_gemm_x6(PatchGeom g, const ClassSpec* css, int ncls, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s);
+
 // single-input-channel special cases (conv_c1.hip)
 int c1_dgrad(const p2i_conv_desc* d, const float* dy, const float* wp_d, const float* add, const float* mask_y, int mask_act,
              float* dx, hipStream_t s);

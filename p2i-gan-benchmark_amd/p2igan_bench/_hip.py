@@ -31,6 +31,8 @@ SIGNATURES = {
     "p2i_conv_fwd": [_D, _P, _P, _P, _P, _P, _I, _P],
     "p2i_conv_dgrad": [_D, _P, _P, _I, _P, _P, _P, _I, _P, _P],
     "p2i_conv_wgrad": [_D, _P, _P, _P, _I, _P, _P, _P],
+    "p2i_conv_fwd_x6": [_D, _P, _P, _P, _P, _P, _P, _I, _P],
+    "p2i_conv_dgrad_x6": [_D, _P, _P, _P, _P, _P, _I, _P, _P],
     "p2i_conv_last_plan": [C.POINTER(C.c_int)],
     "p2i_wgrad_last_plan": [C.POINTER(C.c_int)],
     "p2i_doconv_fold_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],

@@ -79,13 +79,37 @@ def _prof_end(e0, kind, spec, desc, stride1):
         import ctypes
         plan = (ctypes.c_int * 6)()
         _hip.load().p2i_conv_last_plan(plan)
-        if not stride1:
+        if plan[5] == 6:
+            key = "patch_gemm_x6_kernel<%d, %d, %d>%s" % (plan[0], plan[1], plan[2], "" if stride1 else " (strided dgrad classes)")
+        elif not stride1:
             key = "patch_gemm_dma_kernel(strided dgrad: one launch per parity class)"
         elif plan[4] < 0:
             key = "patch_gemm_kernel<%d, %d, %d, %d>" % tuple(plan[:4])
         else:
             key = "patch_gemm_dma_kernel<%d, %d, %d, %d, %d, %d>" % tuple(plan)
     PROFILE.records.append((key, flops, e0, e1))
+
+
+# Convolution engine selection: "f32" (default) = v_mfma_f32_32x32x2_f32 kernels; "x6" = exact-fp32 on the bf16
+# matrix pipe (3-way bf16 split, six MFMA products, csrc/conv_x6.hip; opt-in until it is the faster one).  Both are
+# HIP paths; layers x6 does not cover fall through to the f32 kernels inside the library.
+import os as _os
+
+CONV_ENGINE = _os.environ.get("P2I_CONV_ENGINE", "f32")
+_X6_SCRATCH = {}
+
+
+def _x6_scratch(numel: int, device):
+    """uint16 scratch for the split weights of ONE conv call, reused by every call on the same stream (the split
+    kernel and its consumer are stream-ordered, so the next call may overwrite it)."""
+    if CONV_ENGINE != "x6":
+        return None
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    buf = _X6_SCRATCH.get(key)
+    if buf is None or buf.numel() < numel:
+        buf = torch.empty(max(numel, 1 << 22), device=device, dtype=torch.int16)
+        _X6_SCRATCH[key] = buf
+    return buf
 
 
 def pad32(n: int) -> int:
@@ -142,7 +166,12 @@ def conv_fwd(spec: ConvSpec, x, wp_f, bias=None, residual=None, act=ACT_NONE, ou
     _chk(x, wp_f, bias, residual, y)
     d = spec.desc(b, t, h, w)
     e0 = _prof_begin()
-    _hip.check(lib.p2i_conv_fwd(d, _ptr(x), _ptr(wp_f), _ptr(bias), _ptr(residual), _ptr(y), act, _stream()), "p2i_conv_fwd")
+    ws = _x6_scratch(3 * wp_f.numel(), x.device) if spec.cin % 16 == 0 else None
+    if ws is not None:
+        _hip.check(lib.p2i_conv_fwd_x6(d, _ptr(x), _ptr(wp_f), _ptr(ws), _ptr(bias), _ptr(residual), _ptr(y), act, _stream()),
+                   "p2i_conv_fwd_x6")
+    else:
+        _hip.check(lib.p2i_conv_fwd(d, _ptr(x), _ptr(wp_f), _ptr(bias), _ptr(residual), _ptr(y), act, _stream()), "p2i_conv_fwd")
     _prof_end(e0, "fwd", spec, d, True)
     return y
 
@@ -169,8 +198,13 @@ def conv_dgrad(spec: ConvSpec, dy, wp_d, in_shape, y_act=None, act=ACT_NONE, add
     _chk(dy, wp_d, y_act, dx, add, mask_y)
     d = spec.desc(b, t, h, w)
     e0 = _prof_begin()
-    _hip.check(lib.p2i_conv_dgrad(d, _ptr(dy), _ptr(y_act), act, _ptr(wp_d), _ptr(add), _ptr(mask_y), mask_act, _ptr(dx), _stream()),
-               "p2i_conv_dgrad")
+    ws = _x6_scratch(3 * wp_d.numel(), dy.device) if (y_act is None and spec.cout % 16 == 0 and spec.cin > 1) else None
+    if ws is not None:
+        _hip.check(lib.p2i_conv_dgrad_x6(d, _ptr(dy), _ptr(wp_d), _ptr(ws), _ptr(add), _ptr(mask_y), mask_act, _ptr(dx), _stream()),
+                   "p2i_conv_dgrad_x6")
+    else:
+        _hip.check(lib.p2i_conv_dgrad(d, _ptr(dy), _ptr(y_act), act, _ptr(wp_d), _ptr(add), _ptr(mask_y), mask_act, _ptr(dx), _stream()),
+                   "p2i_conv_dgrad")
     _prof_end(e0, "dgrad", spec, d, spec.stride == (1, 1, 1))
     return dx
 

@@ -50,8 +50,43 @@ def _act_cpu(y, act):
     return {"none": lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.2), "tanh": torch.tanh}[act](y)
 
 
+@pytest.fixture(params=["f32", "x6"])
+def engine(request, ops):
+    """Both convolution engines are held to the same oracle: f32-MFMA kernels (default) and the bf16-split x6 kernels."""
+    old = ops.CONV_ENGINE
+    ops.CONV_ENGINE = request.param
+    yield request.param
+    ops.CONV_ENGINE = old
+
+
+def test_x6_engine_is_used(ops):
+    """The x6 engine must really run (not silently fall through) on the generator's 3x3 C->C layers."""
+    import ctypes
+    old = ops.CONV_ENGINE
+    ops.CONV_ENGINE = "x6"
+    try:
+        spec = ops.ConvSpec(64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+        wp_f, wp_d = ops.weight_pack(_rand(64, 64, 9, seed=1, scale=0.05).cuda())
+        x = _rand(2, 64, 32, 32, seed=2).cuda()
+        plan = (ctypes.c_int * 6)()
+        y = ops.conv_fwd(spec, x, wp_f)
+        ops._hip.load().p2i_conv_last_plan(plan)
+        assert plan[5] == 6, tuple(plan)
+        ops.conv_dgrad(spec, y, wp_d, tuple(x.shape))
+        ops._hip.load().p2i_conv_last_plan(plan)
+        assert plan[5] == 6, tuple(plan)
+        ops.CONV_ENGINE = "f32"
+        y32 = ops.conv_fwd(spec, x, wp_f)
+        ops._hip.load().p2i_conv_last_plan(plan)
+        assert plan[5] != 6
+        # the split drops only products below 2^-23 of a term: both engines agree to fp32 rounding
+        assert rel_err(y.cpu().numpy(), y32.cpu().numpy()) < 5e-6
+    finally:
+        ops.CONV_ENGINE = old
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_fwd_dgrad_wgrad(ops, case):
+def test_conv_fwd_dgrad_wgrad(ops, engine, case):
     name, nd, B, Cin, Cout, sp, k, st, pd, act, has_bias, has_res = case
     act_code = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY, "tanh": ops.ACT_TANH}[act]
     k3 = (1,) + k if nd == 2 else k
