@@ -29,6 +29,9 @@ class FusedAdam:
     def step(self):
         self.step_count += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
+        inval = getattr(self.fp.module, "invalidate_weight_cache", None)   # raw-pointer update: version counters do not see it
+        if inval is not None:
+            inval()
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr, "betas": self.betas, "eps": self.eps}

@@ -24,12 +24,21 @@ BASE_CH = 64
 
 # ----------------------------------------------------------------------------- parameter holders
 class _DOConvParams(nn.Module):
-    """Parameters of DOConv2d (deconv_pytorch.py:52-70): W (O, I/g, k*k), D (I, k*k, k*k), frozen D_diag."""
+    """Parameters of DOConv2d (deconv_pytorch.py:52-70): W (O, I/g, k*k), D (I, k*k, k*k), frozen D_diag.
+    folded=True is DOConv2d_eval (deconv_pytorch.py:133-209): the composite kernel W (O, I/g, k, k) is the only
+    parameter; it runs through the same fold kernel with D + D_diag = identity (non-persistent buffers)."""
 
-    def __init__(self, in_ch: int, out_ch: int, ksz: int, groups: int = 1):
+    def __init__(self, in_ch: int, out_ch: int, ksz: int, groups: int = 1, folded: bool = False):
         super().__init__()
-        self.in_ch, self.out_ch, self.ksz, self.groups = in_ch, out_ch, ksz, groups
+        self.in_ch, self.out_ch, self.ksz, self.groups, self.folded = in_ch, out_ch, ksz, groups, folded
         mn = ksz * ksz
+        if folded:
+            self.W = nn.Parameter(torch.empty(out_ch, in_ch // groups, ksz, ksz))
+            init.kaiming_uniform_(self.W, a=math.sqrt(5))
+            if mn > 1:
+                self.register_buffer("_D0", torch.zeros(in_ch, mn, mn), persistent=False)
+                self.register_buffer("_Dd", torch.eye(mn).reshape(1, mn, mn).repeat(in_ch, 1, 1), persistent=False)
+            return
         self.W = nn.Parameter(torch.empty(out_ch, in_ch // groups, mn))
         init.kaiming_uniform_(self.W, a=math.sqrt(5))
         if mn > 1:
@@ -37,6 +46,9 @@ class _DOConvParams(nn.Module):
             self.D_diag = nn.Parameter(torch.eye(mn).reshape(1, mn, mn).repeat(in_ch, 1, 1), requires_grad=False)
 
     def tensors(self):
+        if self.folded:
+            w = self.W.view(self.out_ch, self.in_ch // self.groups, self.ksz * self.ksz)
+            return (w, self._D0, self._Dd) if self.ksz > 1 else (w, None, None)
         if self.ksz > 1:
             return self.W, self.D, self.D_diag
         return self.W, None, None
@@ -50,14 +62,15 @@ class _Holder(nn.Module):
         self.main = nn.ModuleList(mods)
 
 
-def _basic_conv(in_ch, out_ch, ksz, groups=1):          # BasicConv_do, layer.py:68-94
-    return _Holder([_DOConvParams(in_ch, out_ch, ksz, groups)])
+def _basic_conv(in_ch, out_ch, ksz, groups=1, folded=False):   # BasicConv_do / BasicConv_do_eval, layer.py:68-94
+    return _Holder([_DOConvParams(in_ch, out_ch, ksz, groups, folded)])
 
 
 class _EBlockParams(nn.Module):                          # EBlock / ResBlock_do, p2igan.py:176-183, layer.py:126-135
-    def __init__(self, ch: int, num_res: int):
+    def __init__(self, ch: int, num_res: int, folded: bool = False):
         super().__init__()
-        self.layers = nn.ModuleList([_Holder([_basic_conv(ch, ch, 3), _basic_conv(ch, ch, 3)]) for _ in range(num_res)])
+        self.layers = nn.ModuleList([_Holder([_basic_conv(ch, ch, 3, folded=folded), _basic_conv(ch, ch, 3, folded=folded)])
+                                     for _ in range(num_res)])
 
 
 class _AttnParams(nn.Module):                            # AttentionBlock, layer.py:296-299
@@ -99,17 +112,36 @@ class P2IGenerator(nn.Module):
         self.inference = inference
         # construction order == reference (p2igan.py:44-67) so that torch's RNG is consumed identically
         self.input = _InputParams(depth=2, t=length)
-        self.Decoder = nn.ModuleList([_EBlockParams(BASE_CH << l, num_res) for l in range(4)])
-        self.ConvsOut = nn.ModuleList([_basic_conv(BASE_CH, length, 1, groups=4)])
+        self.Decoder = nn.ModuleList([_EBlockParams(BASE_CH << l, num_res, folded=inference) for l in range(4)])
+        self.ConvsOut = nn.ModuleList([_basic_conv(BASE_CH, length, 1, groups=4, folded=inference)])
         self.UP = nn.ModuleList([
             _UPPosParams(BASE_CH * 2, BASE_CH, self.H, self.W),
             _UPPosParams(BASE_CH * 4, BASE_CH * 2, self.H // 2, self.W // 2),
             _UPPosParams(BASE_CH * 8, BASE_CH * 4, self.H // 4, self.W // 4),
         ])
-        self.Convsin = nn.ModuleList([_basic_conv(length, BASE_CH, 3, groups=4)])
+        self.Convsin = nn.ModuleList([_basic_conv(length, BASE_CH, 3, groups=4, folded=inference)])
         if init_weights:
             self.init_weights()
         self._pnames = [n for n, _ in self.named_parameters()]
+        # packed/folded weights of the last no-grad forward, reused while the parameters are unchanged
+        # (sliding-window inference calls the generator once per window batch): see _cached()
+        self._wp_cache = {}
+        self._weights_epoch = 0
+
+    def invalidate_weight_cache(self):
+        """Must be called by anything that rewrites parameters behind autograd's back (FusedAdam's raw-pointer
+        update does); torch-level writes (load_state_dict, copy_) are seen through the version counters."""
+        self._weights_epoch += 1
+
+    def _cached(self, key, tensors, make):
+        """make() -> packed weights, memoised on (epoch, version counters, storage) of `tensors`."""
+        ver = (self._weights_epoch,) + tuple((t._version, t.data_ptr()) for t in tensors if t is not None)
+        hit = self._wp_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        val = make()
+        self._wp_cache[key] = (ver, val)
+        return val
 
     def init_weights(self, init_type: str = "kaiming", gain: float = 0.02):
         """BaseNetwork.init_weights (layer.py:20-40): only modules exposing `.weight` are touched, i.e. the
@@ -154,6 +186,13 @@ class _GeneratorFn(torch.autograd.Function):
         if h % 8 or w % 8:
             raise RuntimeError("H and W must be multiples of 8")
         need_grad = any(ctx.needs_input_grad[3:])
+        if need_grad and net.inference:
+            raise RuntimeError("P2IGenerator(inference=True) holds folded DO-Conv kernels and is forward-only")
+
+        def fold(conv, out_ch, in_ch, groups, ksz, identity_rep=0):
+            make = lambda: ops.doconv_fold(*conv.tensors(), out_ch, in_ch, groups, ksz, identity_rep=identity_rep, need_d=need_grad)
+            return make() if need_grad else net._cached(id(conv), conv.tensors(), make)
+
         x0 = masked_frames.reshape(b, t, h, w).contiguous().float()
         mk = masks.reshape(b, t, h, w).contiguous().float()
         S = []                                   # saved state for backward
@@ -162,7 +201,7 @@ class _GeneratorFn(torch.autograd.Function):
         idw, sel = ops.idw_fwd(a, mk, tau=0.05, save=need_grad)
         del a
         cin = _doconv_of(net.Convsin[0])
-        wp_in = ops.doconv_fold(*cin.tensors(), BASE_CH, t, 4, 3, identity_rep=4, need_d=need_grad)
+        wp_in = fold(cin, BASE_CH, t, 4, 3, identity_rep=4)
         spec_in = _spec2d(t, BASE_CH, 3)
         x_ = ops.conv_fwd(spec_in, idw, wp_in[0])
         x_2 = ops.pooldup_fwd(x_)
@@ -175,8 +214,8 @@ class _GeneratorFn(torch.autograd.Function):
             rec = []
             for rb in net.Decoder[lvl].layers:
                 c1, c2 = _doconv_of(rb.main[0]), _doconv_of(rb.main[1])
-                w1 = ops.doconv_fold(*c1.tensors(), ch, ch, 1, 3, need_d=need_grad)
-                w2 = ops.doconv_fold(*c2.tensors(), ch, ch, 1, 3, need_d=need_grad)
+                w1 = fold(c1, ch, ch, 1, 3)
+                w2 = fold(c2, ch, ch, 1, 3)
                 y1 = ops.conv_fwd(spec, hcur, w1[0], act=ACT_RELU)
                 hn = ops.conv_fwd(spec, y1, w2[0], residual=hcur)
                 rec.append((hcur, y1, w1[1], w2[1]))
@@ -187,7 +226,8 @@ class _GeneratorFn(torch.autograd.Function):
             up = net.UP[i]
             cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
             u = ops.upmod_fwd(hcur, up.pos)
-            wp = ops.weight_pack(up.proj.weight.reshape(cout_, cin_, 1), need_d=need_grad)
+            pack = lambda: ops.weight_pack(up.proj.weight.reshape(cout_, cin_, 1), need_d=need_grad)
+            wp = pack() if need_grad else net._cached(id(up), (up.proj.weight,), pack)
             r = ops.conv_fwd(_spec2d(cin_, cout_, 1), u, wp[0], bias=up.proj.bias, act=ACT_RELU)
             return r, (hcur, u, r, wp[1])
 
@@ -200,7 +240,7 @@ class _GeneratorFn(torch.autograd.Function):
         res3, up0 = uppos(0, h1)
         h0, rec0 = eblock(0, res3)
         cout = _doconv_of(net.ConvsOut[0])
-        wp_out = ops.doconv_fold(*cout.tensors(), t, BASE_CH, 4, 1, need_d=need_grad)
+        wp_out = fold(cout, t, BASE_CH, 4, 1)
         spec_out = _spec2d(BASE_CH, t, 1)
         z = ops.conv_fwd(spec_out, h0, wp_out[0], act=ACT_TANH)
         if need_grad:
@@ -279,6 +319,31 @@ class _GeneratorFn(torch.autograd.Function):
             out.append(grads.get(id(prm)) if need else None)
         ctx.S = None
         return (None, None, None, *out)
+
+
+def fold_generator_state_dict(sd):
+    """Training checkpoint (W (O,I/g,k*k), D, D_diag per DO-Conv) -> state_dict of P2IGenerator(inference=True)
+    (W (O,I/g,k,k) only): DoW = einsum('ims,ois->oim', D + D_diag, W.reshape(O/g, I, k*k)) reinterpreted as
+    (O, I/g, k, k), exactly DOConv2d.forward (deconv_pytorch.py:111-127).  Checkpoint conversion, not the hot path."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith(".D") or k.endswith(".D_diag"):
+            continue
+        if k.endswith(".W") and v.dim() == 3:
+            O, Ig, mn = v.shape
+            ksz = int(round(mn ** 0.5))
+            dk = k[:-2] + ".D"
+            if dk in sd:
+                D = sd[dk] + sd[k[:-2] + ".D_diag"]
+                I = D.shape[0]
+                g = I // Ig
+                dow = torch.einsum("ims,ois->oim", D, v.reshape(O // g, I, mn))
+                out[k] = dow.reshape(O, Ig, ksz, ksz).contiguous()
+            else:
+                out[k] = v.reshape(O, Ig, ksz, ksz).contiguous()
+        else:
+            out[k] = v
+    return out
 
 
 # ----------------------------------------------------------------------------- discriminator

@@ -36,6 +36,7 @@ class FlatParams:
     one all-reduce."""
 
     def __init__(self, module: nn.Module):
+        self.module = module
         self.params: List[nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device

@@ -27,6 +27,27 @@ def test_state_dict_and_init_match_reference():
     assert [n for n, p in D.named_parameters() if p.requires_grad] == ref["D_trainable"]
 
 
+def test_inference_variant_state_dict_matches_reference():
+    """P2IGenerator(cfg, inference=True) (p2igan.py:36-42): folded DO-Conv kernels W (O, I/g, k, k), no D; same RNG
+    consumption as the reference for the same seed; the checkpoint converter produces a strictly loadable state."""
+    from p2igan_bench.models.p2igan import P2IGenerator, fold_generator_state_dict
+    from p2igan_bench.utils import seeded
+    ref = json.load(open(os.path.join(GOLDEN, "init_32_eval.json")))["G_eval"]
+    torch.manual_seed(1234)
+    G = P2IGenerator(CFG, inference=True)
+    sd = G.state_dict()
+    assert list(sd.keys()) == [r[0] for r in ref]
+    for (k, shape, s, a) in ref:
+        assert list(sd[k].shape) == shape, k
+        assert abs(float(sd[k].double().sum()) - s) <= 1e-9 * max(1.0, a), k
+        assert abs(float(sd[k].double().abs().sum()) - a) <= 1e-9 * max(1.0, a), k
+    folded = fold_generator_state_dict(seeded.seeded_generator_state(32, 32))
+    G.load_state_dict(folded, strict=True)
+    # D = 0 at initialisation => the folded kernel is W itself, reinterpreted
+    w = seeded.seeded_generator_state(32, 32)["ConvsOut.0.main.0.W"]
+    assert torch.equal(folded["ConvsOut.0.main.0.W"].reshape(-1), w.reshape(-1))
+
+
 def test_seeded_recipe_loads_strictly():
     from p2igan_bench.models import build_discriminator, build_generator
     from p2igan_bench.utils import seeded

@@ -252,3 +252,40 @@ def test_two_rank_data_parallel_matches_single_process(dev, tmp_path):
         diff = (flat.cpu() - r0[key]).abs()
         assert float((diff > 5e-5).float().mean()) < 2e-3, key
         assert float(diff.max()) <= 4.1e-4, key
+
+
+def test_inference_variant_and_weight_cache(dev, golden):
+    """P2IGenerator(inference=True) with the converted checkpoint reproduces the reference (eval_variant_32.npz: the
+    reference's own inference=True model, which make_golden.py checked to equal its training variant exactly);
+    repeated no-grad forwards reuse the packed weights until the parameters change."""
+    from p2igan_bench.models.p2igan import P2IGenerator, fold_generator_state_dict
+    from p2igan_bench.utils import seeded
+    g = golden("eval_variant_32.npz")
+    cfg = dict(CFG32, data={"train": {"h": 32, "w": 32, "sample_length": 16}})
+    Ge = P2IGenerator(cfg, inference=True).to(dev)
+    sd = fold_generator_state_dict(seeded.seeded_generator_state(32, 32))
+    Ge.load_state_dict(sd, strict=True)
+    Ge.eval()
+    m0 = seeded.gauge_mask(32, 32, 20)
+    frames, masked, masks = [t.to(dev) for t in seeded.synthetic_batch(1, 16, 32, 32, m0, seed=2024)]
+    with torch.no_grad():
+        y1 = Ge(masked, masks)
+        n_cached = len(Ge._wp_cache)
+        vers = [v[0] for v in Ge._wp_cache.values()]
+        y2 = Ge(masked, masks)
+    assert rel_err(y1.cpu().numpy(), g["preds"]) < TOL
+    assert n_cached == 34 + 3 and [v[0] for v in Ge._wp_cache.values()] == vers      # 32 res convs + in + out, 3 UPPos proj: all hits
+    assert torch.equal(y1, y2)
+    # a torch-level weight change is seen through the version counters ...
+    with torch.no_grad():
+        Ge.ConvsOut[0].main[0].W.mul_(0.5)
+        y3 = Ge(masked, masks)
+    assert not torch.allclose(y3, y1)
+    # ... and the training variant (which folds D every forward when grads are needed) gives the same frames
+    _, G, _ = _build(dev)
+    G.eval()
+    with torch.no_grad():
+        yt = G(masked, masks)
+    assert rel_err(yt.cpu().numpy(), g["preds"]) < TOL
+    with pytest.raises(RuntimeError):          # forward-only: grads w.r.t. folded kernels are not defined by the reference
+        Ge(masked, masks)
