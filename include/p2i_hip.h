@@ -179,6 +179,26 @@ int p2i_gan_loss(const float* logits_a, const float* logits_b, int n, int loss_t
 int p2i_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
              float beta2, float eps, int step, void* stream);
 
+/* ------------------------------------------------------------------ batch assembly
+ * Loader post-processing on the device (sti_dataset.py:209,223-224; train.py:468-473): frames = u8/255,
+ * masks = (mask_u8 != 0), masked = frames*masks, all (B,T,1,H,W) fp32.  mask_u8 has mask_numel elements:
+ * H*W (one gauge map for all frames and samples: `stis`/`sti`), T*H*W or B*T*H*W. */
+int p2i_assemble_batch(const uint8_t* frames_u8, const uint8_t* mask_u8, int64_t mask_numel, float* frames,
+                       float* masked, float* masks, int B, int T, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------ evaluation metrics
+ * metrics/metric.py on the device.  p2i_metrics_pointwise (one pass over pred/target, n elements): sums2[0] += sum|d|,
+ * sums2[1] += sum d^2 with d = T(pred) - T(target), T(x) = 10^(x/16)*0.036 when apply_transform (RegressionMetrics.update
+ * :42-52); counts[k*4 + {0 hits, 1 misses, 2 false alarms, 3 correct negatives}] += ... for T(pred), T(target) >=
+ * thresholds[k] (CategoricalMetrics.update :92-111; always transformed); bits (may be NULL): byte plane, bit k =
+ * T(pred)>=thr[k], bit 4+k = T(target)>=thr[k], the input of p2i_metrics_fss.  thresholds/scales are HOST arrays (<= 4).
+ * p2i_metrics_fss (FractionalSkillScoreMetric.update :152-170): num/den[k*ns + s] += sum over the avg_pool2d(kernel s,
+ * stride 1, padding s/2) fraction fields of (fp-ft)^2 and fp^2+ft^2; the caller divides by N*ho*wo (ho = H+2*(s/2)-s+1). */
+int p2i_metrics_pointwise(const float* pred, const float* target, int64_t n, const float* thresholds_host, int nt,
+                          int apply_transform, float* sums2, unsigned long long* counts, uint8_t* bits, void* stream);
+int p2i_metrics_fss(const uint8_t* bits, int N, int H, int W, int nt, const int* scales_host, int ns, float* num, float* den,
+                    void* stream);
+
 /* small helpers on the same stream */
 int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stream);        /* y += a*x */
 /* out = dy * act'(y) for a saved post-activation tensor y (may alias dy): ReLU / LeakyReLU(0.2) / tanh backward */

@@ -461,3 +461,43 @@ extern "C" int p2i_adam(float* p, const float* g, float* m, float* v, int64_t n,
                      beta2, eps, (float)sqrt(bc2));
   return launch_status();
 }
+
+
+// ------------------------------------------------------------------------------------ batch assembly
+// post_process of the reference loaders (sti_dataset.py:209,223-224: video/255, masked = video*mask) and the
+// (B,T,H,W,C=1)->(B,T,C,H,W) permute of Trainer._prepare_batch (train.py:468-473), on the device: the loader ships
+// uint8 frames and a uint8 mask (12x fewer PCIe bytes than three fp32 tensors).  One pass, 16 pixels per thread.
+namespace p2i {
+__global__ __launch_bounds__(256) void assemble_batch_kernel(const uint8_t* __restrict__ fr, const uint8_t* __restrict__ mk,
+                                                             float* __restrict__ frames, float* __restrict__ masked,
+                                                             float* __restrict__ masks, long long n, long long mask_period) {
+  // mask index = i % mask_period  (mask_period = H*W: one (H,W) mask for every frame of every sample;
+  //                                T*H*W: per-frame masks shared by the samples; B*T*H*W: a mask per voxel)
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  for (long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long i = i0 + q;
+      if (i < n) {
+        const float v = __fdiv_rn((float)fr[i], 255.0f);            // numpy: uint8.astype(float32) / 255.0
+        const float m = mk[i % mask_period] ? 1.0f : 0.0f;
+        frames[i] = v;
+        masks[i] = m;
+        masked[i] = v * m;
+      }
+    }
+  }
+}
+}  // namespace p2i
+
+extern "C" int p2i_assemble_batch(const uint8_t* frames_u8, const uint8_t* mask_u8, int64_t mask_numel, float* frames,
+                                  float* masked, float* masks, int B, int T, int H, int W, void* stream) {
+  P2I_REQUIRE(frames_u8 && mask_u8 && frames && masked && masks, "null pointer");
+  P2I_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0, "bad dims");
+  const long long hw = (long long)H * W, n = (long long)B * T * hw;
+  P2I_REQUIRE(mask_numel == hw || mask_numel == (long long)T * hw || mask_numel == n, "mask must be (H,W), (T,H,W) or (B,T,H,W)");
+  const long long blocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(p2i::assemble_batch_kernel, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                     frames_u8, mask_u8, frames, masked, masks, n, (long long)mask_numel);
+  return p2i::launch_status();
+}

@@ -21,6 +21,8 @@ class P2IDataModule:
         self.persistent_workers = tr.get("persistent_workers", True)
         self.prefetch_factor = tr.get("prefetch_factor", 2)
         self.train_args = self._args(data_cfg["train"])
+        # this build's extension: loaders hand over uint8 frames + uint8 masks, ops.assemble_batch finishes on the device
+        self.train_args["device_assemble"] = bool(tr.get("device_assemble", False))
         shared = {k: deepcopy(self.train_args[k]) for k in ("w", "h", "sample_length", "mask") if k in self.train_args}
         self.valid_dataset = self.test_dataset = None
         self.valid_shuffle = self.test_shuffle = False

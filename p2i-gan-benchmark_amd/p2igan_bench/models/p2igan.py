@@ -168,6 +168,7 @@ class P2IGenerator(nn.Module):
 
     def forward(self, masked_frames, masks):
         params = [p for _, p in self.named_parameters()]
+        self._grad_on = torch.is_grad_enabled()      # Function.forward always runs with grad mode off: capture it here
         return _GeneratorFn.apply(self, masked_frames, masks, *params)
 
 
@@ -185,7 +186,7 @@ class _GeneratorFn(torch.autograd.Function):
             raise RuntimeError(f"generator expects (B,{net.length},1,H,W), got {tuple(masked_frames.shape)}")
         if h % 8 or w % 8:
             raise RuntimeError("H and W must be multiples of 8")
-        need_grad = any(ctx.needs_input_grad[3:])
+        need_grad = net._grad_on and any(ctx.needs_input_grad[3:])
         if need_grad and net.inference:
             raise RuntimeError("P2IGenerator(inference=True) holds folded DO-Conv kernels and is forward-only")
 
@@ -403,6 +404,7 @@ class P2IDiscriminator(nn.Module):
         for m in l2 + l3:
             params += [m.weight_orig, m.bias]
         params.append(self.alpha2d)
+        self._grad_on = torch.is_grad_enabled()
         return _DiscriminatorFn.apply(self, x, *params)
 
 
@@ -416,8 +418,8 @@ class _DiscriminatorFn(torch.autograd.Function):
             raise RuntimeError(f"discriminator expects {net.in_channels} frames, got {t}x{c}")
         xin = x.contiguous().float()
         l2, l3 = net.layers()
-        need_x = ctx.needs_input_grad[1]
-        need_p = any(ctx.needs_input_grad[2:])
+        need_x = net._grad_on and ctx.needs_input_grad[1]
+        need_p = net._grad_on and any(ctx.needs_input_grad[2:])
         training = net.training
 
         def branch(layers, specs, inp):

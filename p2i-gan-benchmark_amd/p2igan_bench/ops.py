@@ -29,7 +29,7 @@ def _chk(*ts):
             continue
         if not (t.is_cuda and t.is_contiguous()):
             raise RuntimeError("p2i ops need contiguous CUDA tensors (the HIP path has no CPU fallback)")
-        if t.dtype not in (torch.float32, torch.int32):
+        if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.int16):
             raise RuntimeError(f"unsupported dtype {t.dtype}")
 
 
@@ -545,3 +545,20 @@ def bias_grad(dy, y_act=None, act=ACT_NONE):
     _chk(dy, y_act)
     _hip.check(lib.p2i_bias_grad(_ptr(dy), _ptr(y_act), act, _ptr(db), B, Cc, inner, _stream()), "p2i_bias_grad")
     return db
+
+
+# --------------------------------------------------------------------------- batch assembly
+def assemble_batch(frames_u8, mask_u8):
+    """uint8 frames (B,T,H,W) + uint8 mask (H,W) | (T,H,W) | (B,T,H,W) -> (frames, masked, masks), each (B,T,1,H,W) fp32:
+    the loader's /255, video*mask and channel permute (sti_dataset.py:209,223-224; train.py:468-473) in one pass."""
+    lib = _hip.load()
+    if frames_u8.dtype != torch.uint8 or mask_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
+        raise RuntimeError("assemble_batch: expects uint8 frames (B,T,H,W) and a uint8 mask")
+    B, T, H, W = frames_u8.shape
+    if tuple(mask_u8.shape) not in ((H, W), (T, H, W), (B, T, H, W)):
+        raise RuntimeError(f"assemble_batch: mask shape {tuple(mask_u8.shape)} does not match frames {tuple(frames_u8.shape)}")
+    _chk(frames_u8, mask_u8)
+    out = [torch.empty((B, T, 1, H, W), device=frames_u8.device, dtype=torch.float32) for _ in range(3)]
+    _hip.check(lib.p2i_assemble_batch(_ptr(frames_u8), _ptr(mask_u8), mask_u8.numel(), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                      B, T, H, W, _stream()), "p2i_assemble_batch")
+    return out[0], out[1], out[2]

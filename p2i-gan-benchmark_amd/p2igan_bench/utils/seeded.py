@@ -154,3 +154,14 @@ def synthetic_batch(b: int, t: int, h: int, w: int, mask_hw: torch.Tensor, seed:
     frames = fr.unsqueeze(2)
     masks = mask_hw.reshape(1, 1, 1, h, w).expand(b, t, 1, h, w).contiguous()
     return frames.contiguous(), (frames * masks).contiguous(), masks
+
+
+def metric_fields(seed: int, n: int = 2, t: int = 16, h: int = 32, w: int = 32):
+    """(preds, target), each (n,t,1,h,w): smooth fields on the 0..64 normalised rain scale, so that the rain-rate
+    transform 10^(x/16)*0.036 of metrics/metric.py crosses its 0.5 / 2 / 4 / 8 mm/h thresholds."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.nn.functional.avg_pool2d(torch.rand(n * t, 1, h + 4, w + 4, generator=g), 5, 1) * 110.0 - 25.0
+    noise = torch.randn(n * t, 1, h, w, generator=g) * 4.0
+    target = base.clamp(min=0.0)
+    preds = (base + noise).clamp(min=0.0)
+    return preds.reshape(n, t, 1, h, w), target.reshape(n, t, 1, h, w)

@@ -18,7 +18,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
-from p2igan_bench import parallel  # noqa: E402
+from p2igan_bench import ops, parallel  # noqa: E402
 from p2igan_bench.data.dataloader import P2IDataModule  # noqa: E402
 from p2igan_bench.engine import TrainEngine  # noqa: E402
 from p2igan_bench.models import build_discriminator, build_generator  # noqa: E402
@@ -114,6 +114,9 @@ class Trainer:
         self.best_val = float("inf")
 
     def _batch(self, batch):
+        if len(batch) == 2:        # train.device_assemble: (uint8 frames (B,T,H,W), uint8 masks) -> fp32 triple on the device
+            fr, mk = (t.to(self.device, non_blocking=True) for t in batch)
+            return list(ops.assemble_batch(fr.contiguous(), mk.contiguous()))
         return [t.permute(0, 1, 4, 2, 3).contiguous().to(self.device, non_blocking=True) for t in batch]   # train.py:468-473
 
     def train(self, tracker):

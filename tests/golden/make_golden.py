@@ -38,6 +38,26 @@ class _Metric(nn.Module):
 
 tm.Metric = _Metric
 sys.modules["torchmetrics"] = tm
+tmi = types.ModuleType("torchmetrics.image")     # metrics/metric.py:11 imports SSIM from here; stubbed (absent library), never used for a golden
+
+
+class _NoSSIM(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+
+    def update(self, *a):
+        pass
+
+    def compute(self):
+        return torch.tensor(float("nan"))
+
+    def reset(self):
+        pass
+
+
+tmi.StructuralSimilarityIndexMeasure = _NoSSIM
+sys.modules["torchmetrics.image"] = tmi
+tm.image = tmi
 sys.path.insert(0, "/root/reference")
 from p2igan_bench.models import build_discriminator, build_generator  # noqa: E402  (reference)
 from p2igan_bench.modules import ReconstructionLoss, gan_loss  # noqa: E402  (reference)
@@ -259,12 +279,38 @@ def case_inference_variant():
     print("inference variant: keys", len(rec["G_eval"]), "eval-vs-train diff", rec["max_abs_diff_eval_vs_train_variant"])
 
 
+def case_metrics():
+    """The reference's own metric classes (metrics/metric.py) on seeded fields: two update() calls, then compute()."""
+    from p2igan_bench.metrics.metric import CategoricalMetrics, FractionalSkillScoreMetric, MetricConfig, RegressionMetrics  # reference
+    cfg = MetricConfig()
+    reg, cat, fs = RegressionMetrics(cfg.apply_transform), CategoricalMetrics(cfg.thresholds), FractionalSkillScoreMetric(cfg.thresholds, cfg.scales)
+    res = {}
+    for i, seed in enumerate((11, 12)):
+        p, t = seeded.metric_fields(seed)
+        reg.update(p, t); cat.update(p, t); fs.update(p, t)
+        res[f"fss_after_{i}"] = np_(fs.score_sum)
+    res["abs_sum"], res["squared_sum"], res["n_obs"] = np_(reg.abs_sum), np_(reg.squared_sum), np_(reg.n_obs)
+    res["table"] = np.stack([np_(cat.hits), np_(cat.misses), np_(cat.false), np_(cat.correct)], axis=1)
+    out = {}
+    out.update({k: v for k, v in reg.compute().items() if k != "ssim"})
+    out.update(cat.compute())
+    out.update(fs.compute())
+    res["keys"] = np.array(sorted(out.keys()))
+    res["values"] = np.array([out[k] for k in sorted(out.keys())], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "metrics_32.npz"), **res)
+    print("metrics:", len(out), "values; table", res["table"].tolist())
+
+
 if __name__ == "__main__":
+    if "--metrics-only" in sys.argv:
+        case_metrics()
+        sys.exit(0)
     if "--inference-variant-only" in sys.argv:
         case_inference_variant()
         sys.exit(0)
     case_init()
     case_inference_variant()
+    case_metrics()
     if "--init-only" in sys.argv:
         sys.exit(0)
     case_idw()

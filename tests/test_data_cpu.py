@@ -55,3 +55,50 @@ def test_synthetic_module_and_test_split_drops_sample_length():
     dm = P2IDataModule(cfg)
     assert next(iter(dm.train_dataloader()))[0].shape == (2, 16, 32, 32, 1)
     assert next(iter(dm.test_dataloader()))[0].shape == (1, 40, 32, 32, 1)
+
+
+def _sti_matrix_reference_loop(H, W, block):
+    """Literal restatement of the per-cell scalar draws of sti_dataset.py:44-58."""
+    m = np.zeros((H, W), dtype=np.float32)
+    for h0 in range(0, H, block):
+        for w0 in range(0, W, block):
+            rh = np.random.randint(h0, min(h0 + block, H))
+            rw = np.random.randint(w0, min(w0 + block, W))
+            m[rh, rw] = 1.0
+    return m
+
+
+def test_vectorised_sti_mask_consumes_numpy_rng_like_the_reference():
+    from p2igan_bench.data.sti_dataset import _sti_matrix
+    for (H, W, b) in [(128, 128, 4), (128, 128, 10), (32, 48, 5), (256, 256, 7), (20, 22, 3)]:
+        np.random.seed(7)
+        a = _sti_matrix_reference_loop(H, W, b)
+        sa = np.random.randint(0, 1 << 30)
+        np.random.seed(7)
+        c = _sti_matrix(H, W, b)
+        sc = np.random.randint(0, 1 << 30)
+        assert np.array_equal(a, c) and sa == sc, (H, W, b)
+
+
+def test_device_assemble_mode_ships_uint8_with_identical_masks(tmp_path):
+    """train.device_assemble: the loader returns (uint8 frames, uint8 mask) drawn with the same RNG calls; the float
+    triple is what ops.assemble_batch rebuilds on the GPU (tests/test_ops_gpu.py)."""
+    from p2igan_bench.data import zarr_lite
+    from p2igan_bench.data.dataloader import P2IDataModule
+    root = tmp_path / "train.zarr"
+    g = zarr_lite.Group(str(root), "w")
+    e = g.require_group("events").require_group("201801010000")
+    e.create_dataset("frames", np.random.default_rng(0).integers(0, 255, (24, 32, 32), dtype=np.uint8), chunks=(20, 16, 16))
+    g.require_group("index").create_dataset("windows", np.array([[0, 0, 16], [0, 4, 16], [0, 8, 16]], dtype=np.int32))
+    base = {"seed": 1, "data": {"train": {"data_root": str(root), "w": 32, "h": 32, "sample_length": 16, "mask": {"type": "sti", "block_sizes": [8]}}},
+            "train": {"batch_size": 1, "num_workers": 0}}
+    ds_f = P2IDataModule(base).train_dataset
+    raw = dict(base, train=dict(base["train"], device_assemble=True))
+    ds_u = P2IDataModule(raw).train_dataset
+    np.random.seed(3)
+    video, masked, mask = ds_f[0]
+    np.random.seed(3)
+    fr_u8, mk_u8 = ds_u[0]
+    assert fr_u8.dtype == torch.uint8 and mk_u8.dtype == torch.uint8 and fr_u8.shape == (16, 32, 32)
+    assert torch.equal(fr_u8.float() / 255.0, video[..., 0]) and torch.equal(mk_u8.float(), mask[..., 0])
+    assert torch.equal((fr_u8.float() / 255.0) * mk_u8.float(), masked[..., 0])

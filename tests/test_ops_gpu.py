@@ -338,3 +338,50 @@ def test_adam_matches_torch(ops):
         ops.adam_step(pg, g.cuda(), m, v, 1e-4, 0.0, 0.99, 1e-8, step)
     assert rel_err(pg.cpu().numpy(), ref.detach().numpy()) < 1e-6
     assert float((pg.cpu() - p).abs().max()) > 1e-5
+
+
+@pytest.mark.parametrize("mshape", ["hw", "thw", "bthw"])
+def test_assemble_batch_bit_exact(ops, mshape):
+    """Loader post-processing on the device == numpy's (uint8 -> float32)/255, video*mask (sti_dataset.py:209,223-224), bit for bit."""
+    B, T, H, W = 3, 16, 24, 40
+    g = torch.Generator().manual_seed(5)
+    fr = torch.randint(0, 256, (B, T, H, W), generator=g, dtype=torch.uint8)
+    mk = (torch.rand({"hw": (H, W), "thw": (T, H, W), "bthw": (B, T, H, W)}[mshape], generator=g) > 0.9).to(torch.uint8)
+    frames, masked, masks = ops.assemble_batch(fr.cuda(), mk.cuda())
+    ef = torch.from_numpy(fr.numpy().astype(np.float32) / 255.0).reshape(B, T, 1, H, W)
+    em = mk.float().expand(B, T, H, W).reshape(B, T, 1, H, W)
+    assert frames.shape == (B, T, 1, H, W)
+    assert torch.equal(frames.cpu(), ef) and torch.equal(masks.cpu(), em) and torch.equal(masked.cpu(), ef * em)
+    with pytest.raises(RuntimeError):
+        ops.assemble_batch(fr.cuda(), mk.cuda()[..., :-1].contiguous())
+
+
+def test_metric_suite_matches_reference_golden(ops, golden):
+    """metrics/metric.py on the HIP path vs the reference's own classes (metrics_32.npz) and the CPU oracle.  The
+    contingency counts depend on powf rounding at the thresholds: the GPU's powf and the reference's CPU pow differ in
+    the last ulp, so a handful of the 131 072 voxels may land on the other side (bound: 8 per cell, documented)."""
+    from oracle import metrics_oracle as mo
+    from p2igan_bench.metrics import MetricConfig, RainfallMetricSuite
+    from p2igan_bench.utils import seeded
+    g = golden("metrics_32.npz")
+    suite = RainfallMetricSuite(MetricConfig()).to("cuda")
+    for seed in (11, 12):
+        p, t = seeded.metric_fields(seed)
+        suite.update(p.cuda(), t.cuda())
+    table = suite.categorical.counts.cpu().view(4, 4).numpy()
+    assert np.abs(table - g["table"].astype(np.int64)).max() <= 8
+    assert table.sum(axis=1).tolist() == [2 * 2 * 16 * 32 * 32] * 4
+    out = suite.compute()
+    vals = dict(zip([str(k) for k in g["keys"]], g["values"]))
+    assert sorted(out.keys()) == sorted(vals.keys())
+    for k, v in vals.items():
+        assert abs(out[k] - v) <= 2e-4 * max(1.0, abs(v)), (k, out[k], v)
+    # second instance, FSS alone on one batch, against the oracle restatement
+    from p2igan_bench.metrics.metric import FractionalSkillScoreMetric
+    p, t = seeded.metric_fields(21, n=1, t=4, h=20, w=28)
+    f = FractionalSkillScoreMetric((0.5, 4.0), (1, 2, 8)).to("cuda")
+    f.update(p.cuda(), t.cuda())
+    ref = mo.fss(p, t, (0.5, 4.0), (1, 2, 8))
+    assert np.allclose(f.score_sum.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-5)
+    suite.reset()
+    assert suite.compute()["mae"] == 0.0

@@ -127,3 +127,31 @@ def test_generator_128_matches_reference(golden):
     assert rel_err(taps["idw"].numpy()[0, :, ::3, ::3], g["idw_s3"]) < 1e-6
     assert rel_err(preds.numpy()[0, :, 0, ::3, ::3], g["preds_s3"]) < TOL
     assert abs(float(preds.double().sum()) - float(g["preds_sum"])) < 1e-4 * float(g["preds_abs_sum"])
+
+
+def test_metrics_oracle_matches_reference_golden(golden):
+    """oracle/metrics_oracle.py vs the reference's own metric classes (metrics_32.npz: two update() calls + compute())."""
+    from oracle import metrics_oracle as mo
+    from p2igan_bench.utils import seeded
+    g = golden("metrics_32.npz")
+    thr, scales = (0.5, 2.0, 4.0, 8.0), (1, 2, 4, 8)
+    table = torch.zeros(4, 4, dtype=torch.int64)
+    fss_sum = torch.zeros(4, 4)
+    abs_sum = sq_sum = 0.0
+    for i, seed in enumerate((11, 12)):
+        p, t = seeded.metric_fields(seed)
+        table += mo.contingency(p, t, thr)
+        fss_sum += mo.fss(p, t, thr, scales)
+        d = mo.transform(p) - mo.transform(t)
+        abs_sum += float(d.abs().sum()); sq_sum += float((d ** 2).sum())
+        assert np.allclose(fss_sum.numpy(), g[f"fss_after_{i}"], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(table.numpy(), g["table"].astype(np.int64))             # integer work: exact
+    assert abs(abs_sum - float(g["abs_sum"])) <= 1e-6 * float(g["abs_sum"])
+    assert abs(sq_sum - float(g["squared_sum"])) <= 1e-6 * float(g["squared_sum"])
+    vals = dict(zip([str(k) for k in g["keys"]], g["values"]))
+    cat = mo.categorical_scores(table, thr)
+    for k, v in cat.items():
+        assert abs(v - vals[k]) <= 1e-6, k
+    for ti, th in enumerate(thr):
+        for si, sc in enumerate(scales):
+            assert abs(float(fss_sum[ti, si] / 2) - vals[f"fss_thr{th:.2f}_s{sc}"]) <= 1e-6
