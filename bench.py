@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", choices=("on", "off"), default="off",
+                    help="replay the whole G+D step as one hipGraph (single GPU).  Off by default: at B=8 the step is bound by "
+                         "kernel time, not by dispatch gaps (28.6 ms replayed vs 28.8 ms eager, profiles/README.md)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,7 +100,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    use_graph = args.graph == "on"
+    done = 0
+    if use_graph and world == 1 and args.warmup >= 1:
+        # the capture's own eager steps are real training steps and count as warm-up; the timed steps are replays of the
+        # captured step (same kernels, same arguments, inputs copied into the captured buffers every step)
+        done = eng.capture(frames, masked, masks, warmup=min(3, args.warmup))
+    for _ in range(max(0, args.warmup - done)):
         eng.train_step(frames, masked, masks)
     sync()
     t0 = time.perf_counter()
@@ -120,11 +129,14 @@ def main():
         # only rank 0 records.
         if rank == 0:
             ops.PROFILE = ops.KernelProfile()
+        graph_saved = getattr(eng, "_graph", None)
+        eng._graph = None                              # events cannot be recorded inside a replay: eager launches here
         nprof = max(2, min(5, args.steps))
         for _ in range(nprof):
             eng.train_step(frames, masked, masks)
         summ = ops.PROFILE.summary() if rank == 0 else None
         ops.PROFILE = None
+        eng._graph = graph_saved
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the conv-engine instance with the largest share of the step (single-kernel keys only)
         single = {k: v for k, v in summ.items() if k.startswith(("patch_gemm_dma_kernel<", "wgrad_dma_kernel<")) and "(" not in k}
@@ -158,7 +170,8 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "configs[1]: p2igan_gan_baseline train step, hinge GAN, B=%d per GPU, T=16, 128x128, 79 gauge points/frame" % B,
-                           "global_batch": B * world, "parallelism": "dp%d" % world},
+                           "global_batch": B * world, "parallelism": "dp%d" % world,
+                           "launch": "hipGraph replay of the whole step" if getattr(eng, "_graph", None) is not None else "eager launches"},
                 "step_tflops": round(GFLOP_PER_SAMPLE_STEP * B * world / (ms_per_step * 1e-3) / 1e3, 2),
                 "roofline": roofline, "cpu_baseline": cpu}
         line.update(extra)

@@ -199,6 +199,12 @@ int p2i_metrics_pointwise(const float* pred, const float* target, int64_t n, con
 int p2i_metrics_fss(const uint8_t* bits, int N, int H, int W, int nt, const int* scales_host, int ns, float* num, float* den,
                     void* stream);
 
+/* Same update with the step counter kept on the device: step_dev[0] is incremented by the call and the bias
+ * corrections are derived from it there (coef2: 2 floats of scratch), so that the launch can be captured in a hipGraph
+ * and replayed every training step. */
+int p2i_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                 float eps, int32_t* step_dev, float* coef2, void* stream);
+
 /* small helpers on the same stream */
 int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stream);        /* y += a*x */
 /* out = dy * act'(y) for a saved post-activation tensor y (may alias dy): ReLU / LeakyReLU(0.2) / tanh backward */

@@ -358,6 +358,27 @@ __global__ void adam_kernel(float* p, const float* __restrict__ g, float* m, flo
   }
 }
 
+// Adam with the step counter on the device (hipGraph replay: a captured launch cannot take a new host scalar per step)
+__global__ void adam_coef_kernel(int32_t* step_dev, float* coef, float lr, float beta1, float beta2) {
+  const int step = step_dev[0] + 1;
+  step_dev[0] = step;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  coef[0] = (float)((double)lr / bc1);
+  coef[1] = (float)sqrt(bc2);
+}
+__global__ void adam_dev_kernel(float* p, const float* __restrict__ g, float* m, float* v, int64_t n, const float* __restrict__ coef,
+                                float beta1, float beta2, float eps) {
+  const float step_size = coef[0], bc2_sqrt = coef[1];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
 static inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
   int64_t g = (n + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -459,6 +480,14 @@ extern "C" int p2i_adam(float* p, const float* g, float* m, float* v, int64_t n,
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(lr / bc1), beta1,
                      beta2, eps, (float)sqrt(bc2));
+  return launch_status();
+}
+
+extern "C" int p2i_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                            int32_t* step_dev, float* coef2, void* stream) {
+  P2I_REQUIRE(p && g && m && v && step_dev && coef2, "bad adam arguments");
+  hipLaunchKernelGGL(adam_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, coef2, lr, beta1, beta2);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, coef2, beta1, beta2, eps);
   return launch_status();
 }
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "p2i_recloss": [_P, _P, _F, _P, _P, _P, _I, _I, _I, _P],
     "p2i_gan_loss": [_P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P],
     "p2i_adam": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P],
+    "p2i_adam_dev": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P, _P],
     "p2i_metrics_pointwise": [_P, _P, _L, C.POINTER(C.c_float), _I, _I, _P, _P, _P, _P],
     "p2i_metrics_fss": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, _P, _P, _P],
     "p2i_assemble_batch": [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -25,10 +25,19 @@ class FusedAdam:
         self.m = torch.zeros_like(fp.flat)
         self.v = torch.zeros_like(fp.flat)
         self.step_count = 0
+        self.step_dev = self.coef = None          # graph mode: step counter + bias corrections on the device
+
+    def use_device_step(self):
+        self.step_dev = torch.tensor([self.step_count], device=self.fp.flat.device, dtype=torch.int32)
+        self.coef = torch.zeros(2, device=self.fp.flat.device, dtype=torch.float32)
 
     def step(self):
         self.step_count += 1
-        ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
+        if self.step_dev is not None:
+            ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
+                              self.step_dev, self.coef)
+        else:
+            ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
         inval = getattr(self.fp.module, "invalidate_weight_cache", None)   # raw-pointer update: version counters do not see it
         if inval is not None:
             inval()
@@ -40,6 +49,8 @@ class FusedAdam:
         self.step_count = int(sd["step"])
         self.m.copy_(sd["exp_avg"])
         self.v.copy_(sd["exp_avg_sq"])
+        if self.step_dev is not None:
+            self.step_dev.fill_(self.step_count)
 
 
 def _allreduce_mean(buf: torch.Tensor, world: int):
@@ -75,8 +86,52 @@ class TrainEngine:
         if self.D is not None:
             broadcast_module_state(self.D, self.dp)
 
+    # ------------------------------------------------------------------ hipGraph replay of the whole step
+    def capture(self, frames, masked, masks, warmup: int = 3):
+        """Capture ONE full G+D iteration (forward, both backward passes, both Adam steps: ~800 launches) into a
+        hipGraph and replay it from then on: the step has no host sync and static shapes, so the ~3-5 us dispatch gap
+        between dependent launches shrinks to the graph's ~1 us.  `warmup` eager steps run first (they are real
+        training steps) so that every lazily built table and kernel attribute exists before the capture.  Single
+        process only: the data-parallel path keeps eager launches around its RCCL exchange."""
+        if self.distributed:
+            raise RuntimeError("graph capture is for the single-GPU step")
+        for o in (self.opt_g, self.opt_d):
+            if o is not None:
+                o.use_device_step()
+        self._static_in = [torch.empty_like(t) for t in (frames, masked, masks)]
+        for dst, src in zip(self._static_in, (frames, masked, masks)):
+            dst.copy_(src)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step_impl(*self._static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_out = self._step_impl(*self._static_in)
+        self._host_steps_per_replay = 1
+        # the capture itself executed nothing: undo the host-side counters it bumped
+        for o in (self.opt_g, self.opt_d):
+            if o is not None:
+                o.step_count -= 1
+        return warmup
+
     def train_step(self, frames, masked, masks) -> Dict[str, torch.Tensor]:
         """One iteration of train.py:240-326.  Returns 0-dim DEVICE tensors (no host sync here)."""
+        if getattr(self, "_graph", None) is not None:
+            for dst, src in zip(self._static_in, (frames, masked, masks)):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+            self._graph.replay()
+            for o in (self.opt_g, self.opt_d):
+                if o is not None:
+                    o.step_count += 1
+            self.G.invalidate_weight_cache() if hasattr(self.G, "invalidate_weight_cache") else None
+            return self._static_out
+        return self._step_impl(frames, masked, masks)
+
+    def _step_impl(self, frames, masked, masks) -> Dict[str, torch.Tensor]:
         self.G.train()
         preds = self.G(masked, masks)
         loss_g, parts = self.rec_loss(preds, frames, masks)

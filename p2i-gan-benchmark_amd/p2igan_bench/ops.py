@@ -517,6 +517,17 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
     _hip.check(lib.p2i_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, step, _stream()), "p2i_adam")
 
 
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_dev, coef):
+    """Adam with the step counter on the device (int32 tensor, incremented by the call): capturable in a hipGraph."""
+    lib = _hip.load()
+    n = p.numel()
+    if not (g.numel() == n and m.numel() == n and v.numel() == n) or step_dev.dtype != torch.int32 or coef.numel() < 2:
+        raise RuntimeError("adam_step_dev: bad buffers")
+    _chk(p, g, m, v, step_dev, coef)
+    _hip.check(lib.p2i_adam_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, _ptr(step_dev), _ptr(coef), _stream()),
+               "p2i_adam_dev")
+
+
 def axpy_(y, x, a=1.0):
     lib = _hip.load()
     if y.numel() != x.numel():
