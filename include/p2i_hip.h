@@ -69,6 +69,12 @@ int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const float* y_act, 
                    float* dx, void* stream);
 int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, const float* y_act,
                    int act, float* dwp, float* dbias, void* stream);
+/* p2i_conv_wgrad with a caller-owned scratch `ws` of ws_floats floats: when it holds every workgroup's partial tile
+ * (<= 256 * kh*kw * Cin * pad32(Cout) floats, 37.7 MB for the generator's 3x3 C->C layers) the partial tiles are stored
+ * and summed by a second kernel instead of being added with float atomics: faster, and bit-reproducible.  ws == NULL or
+ * too small: the atomic path of p2i_conv_wgrad. */
+int p2i_conv_wgrad_ws(const p2i_conv_desc* d, const float* x, const float* dy, const float* y_act, int act, float* dwp,
+                      float* dbias, float* ws, int64_t ws_floats, void* stream);
 /* Same contracts as p2i_conv_fwd / p2i_conv_dgrad (without the act'(y) prologue), computed on the bf16 matrix
  * pipe with fp32 accuracy: every fp32 operand is split exactly into three bf16 terms and six
  * v_mfma_f32_32x32x16_bf16 products are accumulated in fp32 (conv_x6.hip; error <= 2^-22 per product, the

@@ -31,6 +31,7 @@ SIGNATURES = {
     "p2i_conv_fwd": [_D, _P, _P, _P, _P, _P, _I, _P],
     "p2i_conv_dgrad": [_D, _P, _P, _I, _P, _P, _P, _I, _P, _P],
     "p2i_conv_wgrad": [_D, _P, _P, _P, _I, _P, _P, _P],
+    "p2i_conv_wgrad_ws": [_D, _P, _P, _P, _I, _P, _P, _P, _L, _P],
     "p2i_conv_fwd_x6": [_D, _P, _P, _P, _P, _P, _P, _I, _P],
     "p2i_conv_dgrad_x6": [_D, _P, _P, _P, _P, _P, _I, _P, _P],
     "p2i_conv_last_plan": [C.POINTER(C.c_int)],

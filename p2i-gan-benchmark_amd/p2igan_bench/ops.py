@@ -112,6 +112,23 @@ def _x6_scratch(numel: int, device):
     return buf
 
 
+# Weight-gradient partial tiles: stored to a per-stream scratch and summed by a second kernel (deterministic, and faster than
+# 256-way float atomics); P2I_WGRAD_SLICES=0 keeps the atomic path.  256 slices * 9 taps * 64 * 64 floats cover every layer.
+WGRAD_SLICES = _os.environ.get("P2I_WGRAD_SLICES", "1") != "0"
+_WGRAD_WS = {}
+
+
+def _wgrad_scratch(device):
+    if not WGRAD_SLICES:
+        return None
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    buf = _WGRAD_WS.get(key)
+    if buf is None:
+        buf = torch.empty(256 * 9 * 64 * 64 + 1024, device=device, dtype=torch.float32)
+        _WGRAD_WS[key] = buf
+    return buf
+
+
 def pad32(n: int) -> int:
     return (n + 31) // 32 * 32
 
@@ -248,7 +265,12 @@ def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False,
     _chk(x, dy, y_act, dwp, db)
     d = spec.desc(b, t, h, w)
     e0 = _prof_begin()
-    _hip.check(lib.p2i_conv_wgrad(d, _ptr(x), _ptr(dy), _ptr(y_act), act, _ptr(dwp), _ptr(db), _stream()), "p2i_conv_wgrad")
+    ws = _wgrad_scratch(x.device)
+    if ws is not None:
+        _hip.check(lib.p2i_conv_wgrad_ws(d, _ptr(x), _ptr(dy), _ptr(y_act), act, _ptr(dwp), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                   "p2i_conv_wgrad_ws")
+    else:
+        _hip.check(lib.p2i_conv_wgrad(d, _ptr(x), _ptr(dy), _ptr(y_act), act, _ptr(dwp), _ptr(db), _stream()), "p2i_conv_wgrad")
     _prof_end(e0, "wgrad", spec, d, True)
     return dwp, db
 
