@@ -768,7 +768,8 @@ extern "C" int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const flo
         else if (int e = run_patch_gemm(g, cs, (hipStream_t)stream)) return e;
       }
   if (mergeable) {
-    const int rc = ncls > 1 ? run_patch_gemm_classes(g, css, ncls, (hipStream_t)stream) : 1;
+    int rc = (ncls > 1 && x6_ctx().wb == nullptr) ? run_patch_gemm_fused(g, css, ncls, g_last_plan, (hipStream_t)stream) : 1;
+    if (rc == 1) rc = ncls > 1 ? run_patch_gemm_classes(g, css, ncls, (hipStream_t)stream) : 1;
     if (rc == 1) {
       for (int q = 0; q < ncls; ++q)
         if (int e = run_patch_gemm(g, css[q], (hipStream_t)stream)) return e;

@@ -139,6 +139,9 @@ X6Ctx& x6_ctx();
 // returns 1 when no x6 instance fits (caller continues on the fp32-MFMA path)
 int run_patch_gemm_x6(PatchGeom g, const ClassSpec* css, int ncls, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s);
 
+// strided dgrad with the parity classes fused in one workgroup (conv_fused.hip); returns 1 when it does not apply
+int run_patch_gemm_fused(PatchGeom g, const ClassSpec* css, int ncls, int* plan6, hipStream_t s);
+
 // single-input-channel special cases (conv_c1.hip)
 int c1_dgrad(const p2i_conv_desc* d, const float* dy, const float* wp_d, const float* add, const float* mask_y, int mask_act,
              float* dx, hipStream_t s);

@@ -79,7 +79,9 @@ def _prof_end(e0, kind, spec, desc, stride1):
         import ctypes
         plan = (ctypes.c_int * 6)()
         _hip.load().p2i_conv_last_plan(plan)
-        if plan[5] == 6:
+        if plan[5] > 10:
+            key = "patch_gemm_fused_kernel<%d, %d, %d, %d, %d> (strided dgrad, %d parity classes per workgroup)" % (plan[0], plan[1], plan[2], plan[3], plan[5] - 10, plan[5] - 10)
+        elif plan[5] == 6:
             key = "patch_gemm_x6_kernel<%d, %d, %d>%s" % (plan[0], plan[1], plan[2], "" if stride1 else " (strided dgrad classes)")
         elif not stride1:
             key = "patch_gemm_dma_kernel(strided dgrad: one launch per parity class)"

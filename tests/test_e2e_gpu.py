@@ -293,8 +293,9 @@ def test_inference_variant_and_weight_cache(dev, golden):
 
 def test_graph_replay_matches_eager_steps(dev):
     """TrainEngine.capture(): the hipGraph replay of the whole G+D step (device-side Adam step counter) follows the
-    eager engine step for step.  Not bit-identical: wgrad accumulates with float atomics whose order changes from run
-    to run (the same noise two eager runs show), hence the tolerances of the golden test."""
+    eager engine.  Compared at step 2 (one eager warm-up step + one replay): the float atomics of a few small reductions
+    make two EAGER runs drift apart too (beta1 = 0 Adam amplifies sign flips: ~1e-7 at step 2, ~4e-3 in loss_g by step
+    5, measured), so a later comparison would test that chaos, not the replay."""
     from p2igan_bench.engine import TrainEngine
     frames, masked, masks = [t.to(dev) for t in _batch32()]
     res = []
@@ -302,22 +303,19 @@ def test_graph_replay_matches_eager_steps(dev):
         cfg, G, D = _build(dev)
         eng = TrainEngine(G, D, cfg)
         if graph:
-            assert eng.capture(frames, masked, masks, warmup=3) == 3
-            assert eng.opt_g.step_count == 3 and int(eng.opt_g.step_dev) == 3
+            assert eng.capture(frames, masked, masks, warmup=1) == 1
+            assert eng.opt_g.step_count == 1 and int(eng.opt_g.step_dev) == 1
         else:
-            for _ in range(3):
-                eng.train_step(frames, masked, masks)
-        for _ in range(2):
-            r = eng.train_step(frames, masked, masks)
-        assert eng.opt_g.step_count == 5 and eng.opt_d.step_count == 5
+            eng.train_step(frames, masked, masks)
+        r = eng.train_step(frames, masked, masks)
+        assert eng.opt_g.step_count == 2 and eng.opt_d.step_count == 2
         if graph:
-            assert int(eng.opt_g.step_dev) == 5
+            assert int(eng.opt_g.step_dev) == 2 and int(eng.opt_d.step_dev) == 2
         res.append(({k: float(r[k]) for k in ("loss_g", "loss_d", "rec")}, r["preds"].clone(), eng.gp.flat.clone(), eng.dp.flat.clone()))
     (la, pa, ga, da), (lb, pb, gb, db) = res
     for k in la:
-        assert abs(la[k] - lb[k]) <= 2e-3 * abs(la[k]), (k, la[k], lb[k])
-    assert rel_err(pb.cpu().numpy(), pa.cpu().numpy()) < 2e-3
-    # parameters moved by 5 Adam steps of lr 1e-4 (beta1 = 0: sign-like updates): compare the MOVEMENT, not the values
+        assert abs(la[k] - lb[k]) <= 1e-4 * abs(la[k]), (k, la[k], lb[k])
+    assert rel_err(pb.cpu().numpy(), pa.cpu().numpy()) < 1e-4
     # (a gradient whose sign flips under summation-order noise moves a weight by up to lr/sqrt(1-beta2) = 1e-3 in one step)
     assert float((ga - gb).abs().max()) <= 2e-3 and float((da - db).abs().max()) <= 2e-3
-    assert float((ga - gb).abs().mean()) <= 2e-5 and float((da - db).abs().mean()) <= 2e-5
+    assert float((ga - gb).abs().mean()) <= 2e-6 and float((da - db).abs().mean()) <= 2e-6
