@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
   const int* c_tap_off = multi ? cg.tap_off : g.tap_off;
   const int nwrows = g.ntaps * CK;
   const int WSZ = ((nwrows * V + 63) & ~63) * 4;     // weight floats per chunk (padded to whole wave-instructions)
-  const int PTp = (g.PT + 63) & ~63;                 // patch dwords per chunk, padded to a wave-instruction
+  // patch dwords per chunk, padded to whole wave-instructions (v4: 64 lanes x 16 B)
+  const int PT4p = ((g.PT >> 2) + 63) & ~63;
+  const int PTp = g.v4 ? PT4p * 4 : (g.PT + 63) & ~63;
   int* wtab = reinterpret_cast<int*>(smem);          // [nwrows] (padded to 64)
   const int wtab_sz = (nwrows + 63) & ~63;
   int* ptab = wtab + wtab_sz;                        // [PTp]
@@ -219,6 +221,27 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
     }
     wtab[r] = off;
   }
+  if (g.v4) {
+    // 16 B per lane: the image rows start at a 16-B aligned source column (host shifted the origin left and padded the
+    // row to a multiple of 4), so a 4-pixel group is inside the tensor or outside it as a whole (sW % 4 == 0)
+    for (int e = tid; e < PT4p; e += NTH) {
+      int off = -16;
+      if (e < (g.PT >> 2)) {
+        const int c = fast_div(e, g.mg_g4);
+        int rem = e - c * g.G4;
+        const int row = g.eW4 == 1 ? rem : fast_div(rem, g.mg_ew4);      // (the magic multiplier does not exist for d = 1)
+        const int g4 = rem - row * g.eW4;
+        const int jb = fast_div(row, g.mg_eth);
+        int r2 = row - jb * g.eth;
+        const int et = fast_div(r2, g.mg_eh);
+        const int eh = r2 - et * g.eH;
+        const int b = j0b + jb, t = src_t0 + et, h = src_h0 + eh, w = src_w0 + 4 * g4;
+        if (b < g.B && c < g.Ck && (unsigned)t < (unsigned)g.sT && (unsigned)h < (unsigned)g.sH && (unsigned)w < (unsigned)g.sW)
+          off = ((((b * g.Ck + c) * g.sT + t) * sHW) + h * g.sW + w) * 4;
+      }
+      ptab[e] = off;
+    }
+  } else
   for (int e = tid; e < PTp; e += NTH) {
     int off = -4;
     if (e < g.PT) {
@@ -279,6 +302,14 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
     }
     const int pbo = bufoff + WSZ;
     const int p_soff = c0 * chan_bytes;
+    if (g.v4) {
+      for (int e0 = 0; e0 < PT4p; e0 += NTH) {       // patch: 16 B per lane (a quarter of the DMA instructions)
+        const int e = e0 + tid;
+        const int voff = e < PT4p ? ptab[e] : -16;
+        if (e0 + wbase < PT4p)
+          dma_b128(rs_src, smem_la + 4u * (pbo + (e0 + wbase) * 4), voff, p_soff);
+      }
+    } else
     for (int e0 = 0; e0 < PTp; e0 += NTH) {          // patch: 4 B per lane
       const int e = e0 + tid;
       const int voff = e < PTp ? ptab[e] : -4;
@@ -549,11 +580,22 @@ static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, h
     t.eT = (jt - 1) * g.mT + rng[0] + 1;
     t.eH = (jh - 1) * g.mH + rng[1] + 1;
     t.eW = (jw - 1) * g.mW + rng[2] + 1;
+    // 16-B patch DMA: single class, unit source multiplier along w, rows and tile origins 16-B aligned
+    const char* v4_env = getenv("P2I_CONV_V4");            // read per call: tools/v4_check.py toggles it in-process
+    const int v4_off = v4_env ? (atoi(v4_env) == 0) : 0;
+    t.v4 = (!v4_off && ncls == 1 && g.mW == 1 && (g.sW & 3) == 0 && jw >= 4) ? 1 : 0;
+    t.v4sh = 0;
+    if (t.v4) {
+      t.v4sh = ((lo[0][2] % 4) + 4) % 4;                    // columns added on the left so that the row starts 16-B aligned
+      t.eW = (t.eW + t.v4sh + 3) & ~3;
+      t.eW4 = t.eW >> 2;
+    }
     t.eWp = t.eW;
     t.eth = t.eT * t.eH;
     t.rpc = jb * t.eth;
     t.CSl = t.rpc * t.eW;
     t.CS = t.CSl;
+    t.G4 = t.CSl >> 2;
     static const int force_ck16 = getenv("P2I_CONV_CK16") ? atoi(getenv("P2I_CONV_CK16")) : 0;
     for (int CKc = ((max_taps <= 4 || ((force_ck16 || g.Ck >= 256) && max_taps == 9 && MBc <= 64)) ? 16 : 8); CKc >= 2; CKc >>= 1) {
       if (g.Ck >= CKc ? (g.Ck % CKc != 0) : (CKc != 2 && g.Ck * 2 <= CKc)) continue;
@@ -561,7 +603,7 @@ static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, h
       if ((CKc == 4 || CKc == 16) && MBc == 128 && NP == 128) continue;
       const int PT = CKc * t.CSl;
       if (PT >= 65536 || t.CSl >= 65536) continue;
-      const int PTp = (PT + 63) & ~63;
+      const int PTp = t.v4 ? (((PT >> 2) + 63) & ~63) * 4 : (PT + 63) & ~63;
       const int nwrows = max_taps * CKc;
       const size_t WSZ = (size_t)((nwrows * (MBc / 4) + 63) & ~63) * 4;
       const size_t lds = sizeof(float) * (((nwrows + 63) & ~63) + (size_t)PTp + 2 * (WSZ + PTp));
@@ -583,6 +625,7 @@ static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, h
   TileCfg c{cand[best][0], cand[best][1], cand[best][2], best_ck};
   bg.mg_csl = magic_u16(bg.CSl); bg.mg_ew = magic_u16(bg.eW);
   bg.mg_rpc = magic_u16(bg.rpc); bg.mg_eth = magic_u16(bg.eth); bg.mg_eh = magic_u16(bg.eH);
+  if (bg.v4) { bg.mg_g4 = magic_u16(bg.G4); bg.mg_ew4 = magic_u16(bg.eW4); }
   bg.src_bytes = (unsigned)sbytes;
   bg.wp_bytes = g.wp_bytes;
   bg.nclass = ncls;
@@ -603,6 +646,10 @@ static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, h
   bg.pT = css[0].pT; bg.pH = css[0].pH; bg.pW = css[0].pW;
   bg.bT = lo[0][0]; bg.bH = lo[0][1]; bg.bW = lo[0][2];
   for (int i = 0; i < css[0].ntaps; ++i) { bg.tap_w[i] = bg.cls[0].tap_w[i]; bg.tap_off[i] = bg.cls[0].tap_off[i]; }
+  if (bg.v4) {                                               // aligned origin: v4sh columns further left
+    bg.bW -= bg.v4sh; bg.cls[0].bW -= bg.v4sh;
+    for (int i = 0; i < css[0].ntaps; ++i) { bg.tap_off[i] += bg.v4sh; bg.cls[0].tap_off[i] += bg.v4sh; }
+  }
   if (ncls == 1) bg.ntaps = css[0].ntaps;
   // ~1 workgroup per CU or fewer: 8-wave workgroups with intra-block split-K (small accumulator tiles only)
   const long long nb = (long long)best_grid.x * best_grid.y * best_grid.z;

@@ -113,6 +113,9 @@ struct PatchGeom {
   int PT;               // patch dwords per chunk = CK * CSl
   unsigned src_bytes, wp_bytes;
   unsigned mg_csl, mg_ew;
+  int v4, v4sh;         // DMA variant: 16-B patch DMA (rows start v4sh columns left of the tap window, 16-B aligned)
+  int eW4, G4;          // row pitch and channel stride in 4-pixel groups
+  unsigned mg_g4, mg_ew4;
   // ---- x6 (bf16-split) variant only
   const uint16_t* wb;   // split weights [plane 3][ntaps_w][Ck/8][CmPad][8] bf16
   unsigned wb_bytes;
