@@ -245,7 +245,11 @@ int run_patch_gemm_fused(PatchGeom g, const ClassSpec* css, int ncls, int* plan6
   if (mx[0] <= 0 || mx[1] <= 0 || mx[2] <= 0 || ntt == 0 || ntt > MAX_TAPS) return 1;
   g.mT = g.mH = g.mW = 1;
   g.oT = c0s.oT; g.oH = c0s.oH; g.oW = c0s.oW;
-  const int MBc = g.Cm > 32 ? 64 : 32, NP = 128, WM = MBc == 64 ? 2 : 1;
+  // 64-channel m-tiles unless that leaves half of the CUs without a workgroup (deep, small layers)
+  long long px = 0;
+  for (int q = 0; q < ncls; ++q) px = px > (long long)g.B * css[q].nT * css[q].nH * css[q].nW ? px : (long long)g.B * css[q].nT * css[q].nH * css[q].nW;
+  const bool few = g.Cm > 32 && (long long)ceil_div(g.Cm, 64) * ((px + 127) / 128) < 200;
+  const int MBc = (g.Cm > 32 && !few) ? 64 : 32, NP = 128, WM = MBc == 64 ? 2 : 1;
   const int CKc = ntt <= 9 ? 16 : 4;
   if (g.Ck % CKc != 0) return 1;
   int jb, jt, jh, jw;
