@@ -131,11 +131,22 @@ class TrainEngine:
             return self._static_out
         return self._step_impl(frames, masked, masks)
 
+    def _mark(self):
+        """Phase boundary for bench.py's G-step / D-step split (HIP events on the launch stream; off unless asked for)."""
+        if self.phase_marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.phase_marks.append(e)
+
+    phase_marks = None      # set to [] to collect 4 events per step: start, after G fwd + rec loss, after the D step, end
+
     def _step_impl(self, frames, masked, masks) -> Dict[str, torch.Tensor]:
+        self._mark()
         self.G.train()
         preds = self.G(masked, masks)
         loss_g, parts = self.rec_loss(preds, frames, masks)
         out = {"rec": loss_g.detach(), "pool": parts["pool"].tensor(), "reg": parts["reg"].tensor()}
+        self._mark()
         if self.use_gan:
             self.D.train()
             for p in self.dp.params:
@@ -150,6 +161,7 @@ class TrainEngine:
             self.opt_d.step()
             for p in self.dp.params:
                 p.requires_grad_(False)
+            self._mark()
             logits_g = self.D(preds)
             adv = generator_adv_loss(logits_g, self.adv_weight, self.gan_type, self.real_label)
             loss_g = loss_g + adv
@@ -163,6 +175,7 @@ class TrainEngine:
             for p in self.dp.params:
                 p.requires_grad_(True)
         out.update(loss_g=loss_g.detach(), preds=preds.detach())
+        self._mark()
         return out
 
     @torch.no_grad()
