@@ -385,3 +385,22 @@ def test_metric_suite_matches_reference_golden(ops, golden):
     assert np.allclose(f.score_sum.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-5)
     suite.reset()
     assert suite.compute()["mae"] == 0.0
+
+
+def test_wgrad_slices_are_bit_reproducible_and_match_atomics(ops):
+    """p2i_conv_wgrad_ws: partial tiles stored and summed by wgrad_reduce_kernel -> the same bits on every run (the
+    atomic path only agrees to summation-order noise), for a split-heavy layer (64 channels: 256 slices) and a deep one."""
+    for (B, C, S) in [(4, 64, 64), (2, 256, 16)]:
+        spec = ops.ConvSpec(C, C, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+        x, dy = _rand(B, C, S, S, seed=1).cuda(), _rand(B, C, S, S, seed=2).cuda()
+        old = ops.WGRAD_SLICES
+        try:
+            ops.WGRAD_SLICES = True
+            a, _ = ops.conv_wgrad(spec, x, dy)
+            b, _ = ops.conv_wgrad(spec, x, dy)
+            ops.WGRAD_SLICES = False
+            c, _ = ops.conv_wgrad(spec, x, dy)
+        finally:
+            ops.WGRAD_SLICES = old
+        assert torch.equal(a, b)
+        assert rel_err(a.cpu().numpy(), c.cpu().numpy()) < 1e-5
