@@ -32,6 +32,8 @@ struct WgradGeom {
   int tap_offq[9];       // tap offsets in the [row][c][eWq] image
   unsigned mg_ewq, mg_pp, x_bytes, dy_bytes;
   int dbg;               // diagnostics only (P2I_WGRAD_DBG): 1 = skip MFMA, 2 = skip DMA after the first tile
+  int x4, x4sh;          // x image filled by 16-B DMA: rows start x4sh columns left of the tap window (16-B aligned)
+  unsigned mg_ewq4;
   float* partial;        // != null: workgroup blockIdx.x STORES its partial tile to partial + blockIdx.x * pstride (same
   long long pstride;     // [tap][c][o] indexing as dwp) instead of atomically adding it; wgrad_reduce_kernel sums the slices
 };
@@ -250,6 +252,19 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
       const int b = j0b + jb, h = sh0 + eh;
       const bool rok = tvalid && b < g.B && (unsigned)h < (unsigned)g.sH;
       const int rbase = ((b * g.Cx + c0) * g.sT + st) * sHW + h * g.sW + sw0;
+      if (g.x4) {
+        // 16 B per lane: rows start at a 16-B aligned source column (sw0 % 4 == 0, sW % 4 == 0), pitch eWq = 4 * odd
+        // (2-way bank conflict on the per-channel A reads, a quarter of the DMA instructions)
+        const int rb4 = rowblk >> 2;
+        for (int e0 = 0; e0 < rb4; e0 += 512) {
+          const int e = e0 + tid;
+          const int cc = fast_div(e, g.mg_ewq4);
+          const int g4 = e - cc * (g.eWq >> 2);
+          const bool ok = rok && cc < CB && c0 + cc < g.Cx && (unsigned)(sw0 + 4 * g4) < (unsigned)g.sW;
+          const int voff = ok ? (rbase + cc * g.sT * sHW + 4 * g4) * 4 : -16;
+          if (e0 + wbase < rb4) dma_b128(rs_x, smem_la + 4u * (bufoff + prow * rowblk + (e0 + wbase) * 4), voff, 0);
+        }
+      } else
       for (int e0 = 0; e0 < rowblk; e0 += 512) {
         const int e = e0 + tid;
         const int cc = fast_div(e, g.mg_ewq);
@@ -501,11 +516,22 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
     const bool y4 = (d->Wo % 4 == 0);
     const int PPh = y4 ? NPIX + 4 : NPIX + 1;
     g.eWq = g.eW | 1;
+    {
+      const char* e4 = getenv("P2I_WGRAD_X4");
+      g.x4 = (!(e4 && atoi(e4) == 0) && d->sw == 1 && (d->Wi & 3) == 0 && jw >= 4) ? 1 : 0;
+      g.x4sh = 0;
+      if (g.x4) {
+        g.x4sh = (((-d->pw) % 4) + 4) % 4;
+        g.eWq = (g.eW + g.x4sh + 3) & ~3;
+        if (((g.eWq >> 2) & 1) == 0) g.eWq += 4;          // pitch = 4 * odd: 16 distinct banks for 32 consecutive channels
+        g.mg_ewq4 = (g.eWq >> 2) == 1 ? 0u : magic_u16(g.eWq >> 2);
+      }
+    }
     const unsigned long long xb = 4ull * d->B * d->Cin * d->Ti * d->Hi * d->Wi, yb = 4ull * d->B * d->Cout * d->To * d->Ho * d->Wo;
     int CBh = d->Cin > 32 ? 64 : 32;
     size_t lds2 = 0;
     for (;;) {
-      g.rowblk = (CBh * g.eWq + 63) & ~63;
+      g.rowblk = g.x4 ? (CBh * g.eWq + 255) & ~255 : (CBh * g.eWq + 63) & ~63;
       g.XSZ = jb * g.eH * g.rowblk;
       lds2 = sizeof(float) * 2 * ((size_t)((g.XSZ + 3) & ~3) + (size_t)((64 * PPh + 255) / 256) * 256);
       { const size_t red = sizeof(float) * 3 * 4 * 16 * 64 * 2; if (lds2 < red) lds2 = red; }   // k-split combine scratch
@@ -537,7 +563,8 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
         ga.nsplit = ns;
         ga.dwp = dwp + (size_t)a * g.tpg * d->Cin * g.CoPad;
         for (int b = 0; b < d->kh; ++b)
-          for (int c = 0; c < d->kw; ++c) ga.tap_offq[b * d->kw + c] = b * g.rowblk + c;
+          for (int c = 0; c < d->kw; ++c) ga.tap_offq[b * d->kw + c] = b * g.rowblk + c + g.x4sh;
+        if (g.x4) ga.bW = g.bW - g.x4sh;
         // slice mode: ns >= 2 partial tiles per output element and a scratch that holds all ns slices of this launch
         const long long slice = (long long)g.tpg * d->Cin * g.CoPad;
         const bool sliced = ns >= 2 && g_wgrad_ws != nullptr && slice * ns <= g_wgrad_ws_floats && slice < (1ll << 31);
