@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void patch_gemm_fused_kernel(const PatchGeom g
   constexpr int V = MB / 4;                          // float4 per weight row
   const int nwrows = g.ntaps * CK;                   // g.ntaps = taps of all classes, concatenated class by class
   const int WSZ = ((nwrows * V + 63) & ~63) * 4;
-  const int PTp = (g.PT + 63) & ~63;
+  const int PT4p = ((g.PT >> 2) + 63) & ~63;
+  const int PTp = g.v4 ? PT4p * 4 : (g.PT + 63) & ~63;
   int* wtab = reinterpret_cast<int*>(smem);
   const int wtab_sz = (nwrows + 63) & ~63;
   int* ptab = wtab + wtab_sz;
@@ -50,6 +51,25 @@ __global__ __launch_bounds__(256) void patch_gemm_fused_kernel(const PatchGeom g
     }
     wtab[r] = off;
   }
+  if (g.v4) {                                        // 16-B patch DMA: see patch_gemm_dma_kernel (conv.hip)
+    for (int e = tid; e < PT4p; e += 256) {
+      int off = -16;
+      if (e < (g.PT >> 2)) {
+        const int c = fast_div(e, g.mg_g4);
+        int rem = e - c * g.G4;
+        const int row = g.eW4 == 1 ? rem : fast_div(rem, g.mg_ew4);
+        const int g4 = rem - row * g.eW4;
+        const int jb = fast_div(row, g.mg_eth);
+        int r2 = row - jb * g.eth;
+        const int et = fast_div(r2, g.mg_eh);
+        const int eh = r2 - et * g.eH;
+        const int b = j0b + jb, t = src_t0 + et, h = src_h0 + eh, w = src_w0 + 4 * g4;
+        if (b < g.B && c < g.Ck && (unsigned)t < (unsigned)g.sT && (unsigned)h < (unsigned)g.sH && (unsigned)w < (unsigned)g.sW)
+          off = ((((b * g.Ck + c) * g.sT + t) * sHW) + h * g.sW + w) * 4;
+      }
+      ptab[e] = off;
+    }
+  } else
   for (int e = tid; e < PTp; e += 256) {
     int off = -4;
     if (e < g.PT) {
@@ -112,6 +132,13 @@ __global__ __launch_bounds__(256) void patch_gemm_fused_kernel(const PatchGeom g
     }
     const int pbo = bufoff + WSZ;
     const int p_soff = c0 * chan_bytes;
+    if (g.v4) {
+      for (int e0 = 0; e0 < PT4p; e0 += 256) {
+        const int e = e0 + tid;
+        const int voff = e < PT4p ? ptab[e] : -16;
+        if (e0 + wbase < PT4p) dma_b128(rs_src, smem_la + 4u * (pbo + (e0 + wbase) * 4), voff, p_soff);
+      }
+    } else
     for (int e0 = 0; e0 < PTp; e0 += 256) {
       const int e = e0 + tid;
       const int voff = e < PTp ? ptab[e] : -4;
@@ -258,6 +285,16 @@ int run_patch_gemm_fused(PatchGeom g, const ClassSpec* css, int ncls, int* plan6
   g.eT = (jt - 1) + hi[0] - lo[0] + 1;
   g.eH = (jh - 1) + hi[1] - lo[1] + 1;
   g.eW = (jw - 1) + hi[2] - lo[2] + 1;
+  {
+    const char* v4_env = getenv("P2I_CONV_V4");
+    g.v4 = (!(v4_env && atoi(v4_env) == 0) && (g.sW & 3) == 0 && jw >= 4) ? 1 : 0;
+    g.v4sh = 0;
+    if (g.v4) {
+      g.v4sh = ((lo[2] % 4) + 4) % 4;
+      g.eW = (g.eW + g.v4sh + 3) & ~3;
+      g.eW4 = g.eW >> 2;
+    }
+  }
   g.eWp = g.eW;
   g.eth = g.eT * g.eH;
   g.rpc = jb * g.eth;
@@ -265,18 +302,20 @@ int run_patch_gemm_fused(PatchGeom g, const ClassSpec* css, int ncls, int* plan6
   g.CS = g.CSl;
   g.PT = CKc * g.CSl;
   if (g.PT >= 65536 || g.CSl >= 65536) return 1;
-  const int PTp = (g.PT + 63) & ~63;
+  const int PTp = g.v4 ? (((g.PT >> 2) + 63) & ~63) * 4 : (g.PT + 63) & ~63;
   const int nwrows = ntt * CKc;
+  g.G4 = g.CSl >> 2;
   const size_t WSZ = (size_t)((nwrows * (MBc / 4) + 63) & ~63) * 4;
   const size_t lds = sizeof(float) * (((nwrows + 63) & ~63) + (size_t)PTp + 2 * (WSZ + PTp));
   const unsigned long long sbytes = 4ull * g.B * g.Ck * g.sT * g.sH * g.sW;
   if (lds > 160 * 1024 || sbytes >= 0xF0000000ull) return 1;
   g.mg_csl = magic_u16(g.CSl); g.mg_ew = magic_u16(g.eW);
+  if (g.v4) { g.mg_g4 = magic_u16(g.G4); g.mg_ew4 = magic_u16(g.eW4); }
   g.mg_rpc = magic_u16(g.rpc); g.mg_eth = magic_u16(g.eth); g.mg_eh = magic_u16(g.eH);
   g.src_bytes = (unsigned)sbytes;
   g.nclass = ncls;
   g.ntaps = ntt;
-  g.bT = lo[0]; g.bH = lo[1]; g.bW = lo[2];
+  g.bT = lo[0]; g.bH = lo[1]; g.bW = lo[2] - g.v4sh;          // v4: aligned origin, v4sh columns further left
   g.nT = mx[0]; g.nH = mx[1]; g.nW = mx[2];
   int tix = 0;
   for (int q = 0; q < ncls; ++q) {
@@ -288,7 +327,7 @@ int run_patch_gemm_fused(PatchGeom g, const ClassSpec* css, int ncls, int* plan6
     cgm.ntaps = cs.ntaps;
     for (int i = 0; i < cs.ntaps; ++i, ++tix) {
       g.tap_w[tix] = cs.tw[i];
-      g.tap_off[tix] = ((cs.dt[i] - lo[0]) * g.eH + (cs.dh[i] - lo[1])) * g.eW + (cs.dw[i] - lo[2]);
+      g.tap_off[tix] = ((cs.dt[i] - lo[0]) * g.eH + (cs.dh[i] - lo[1])) * g.eW + (cs.dw[i] - lo[2]) + g.v4sh;
     }
   }
   g.ntt = ceil_div(mx[0], jt); g.nth = ceil_div(mx[1], jh); g.ntw = ceil_div(mx[2], jw);
