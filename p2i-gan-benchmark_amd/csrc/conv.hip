@@ -580,10 +580,10 @@ static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, h
     t.eT = (jt - 1) * g.mT + rng[0] + 1;
     t.eH = (jh - 1) * g.mH + rng[1] + 1;
     t.eW = (jw - 1) * g.mW + rng[2] + 1;
-    // 16-B patch DMA: single class, unit source multiplier along w, rows and tile origins 16-B aligned
+    // 16-B patch DMA: single class, rows and tile origins 16-B aligned
     const char* v4_env = getenv("P2I_CONV_V4");            // read per call: tools/v4_check.py toggles it in-process
     const int v4_off = v4_env ? (atoi(v4_env) == 0) : 0;
-    t.v4 = (!v4_off && ncls == 1 && g.mW == 1 && (g.sW & 3) == 0 && jw >= 4) ? 1 : 0;
+    t.v4 = (!v4_off && ncls == 1 && (g.sW & 3) == 0 && ((jw * g.mW) & 3) == 0) ? 1 : 0;   // any source multiplier: rows are contiguous
     t.v4sh = 0;
     if (t.v4) {
       t.v4sh = ((lo[0][2] % 4) + 4) % 4;                    // columns added on the left so that the row starts 16-B aligned

@@ -518,7 +518,7 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
     g.eWq = g.eW | 1;
     {
       const char* e4 = getenv("P2I_WGRAD_X4");
-      g.x4 = (!(e4 && atoi(e4) == 0) && d->sw == 1 && (d->Wi & 3) == 0 && jw >= 4) ? 1 : 0;
+      g.x4 = (!(e4 && atoi(e4) == 0) && (d->Wi & 3) == 0 && ((jw * d->sw) & 3) == 0) ? 1 : 0;
       g.x4sh = 0;
       if (g.x4) {
         g.x4sh = (((-d->pw) % 4) + 4) % 4;
