@@ -580,10 +580,12 @@ static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, h
     t.eT = (jt - 1) * g.mT + rng[0] + 1;
     t.eH = (jh - 1) * g.mH + rng[1] + 1;
     t.eW = (jw - 1) * g.mW + rng[2] + 1;
-    // 16-B patch DMA: single class, rows and tile origins 16-B aligned
+    // 16-B patch DMA: rows and tile origins 16-B aligned
     const char* v4_env = getenv("P2I_CONV_V4");            // read per call: tools/v4_check.py toggles it in-process
     const int v4_off = v4_env ? (atoi(v4_env) == 0) : 0;
-    t.v4 = (!v4_off && ncls == 1 && (g.sW & 3) == 0 && ((jw * g.mW) & 3) == 0) ? 1 : 0;   // any source multiplier: rows are contiguous
+    bool same_lo_w = true;                                  // merged classes may share the aligned origin only if their w windows start alike
+    for (int q = 1; q < ncls; ++q) same_lo_w = same_lo_w && lo[q][2] == lo[0][2];
+    t.v4 = (!v4_off && same_lo_w && (g.sW & 3) == 0 && ((jw * g.mW) & 3) == 0) ? 1 : 0;   // any source multiplier: rows are contiguous
     t.v4sh = 0;
     if (t.v4) {
       t.v4sh = ((lo[0][2] % 4) + 4) % 4;                    // columns added on the left so that the row starts 16-B aligned
@@ -647,8 +649,12 @@ static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, h
   bg.bT = lo[0][0]; bg.bH = lo[0][1]; bg.bW = lo[0][2];
   for (int i = 0; i < css[0].ntaps; ++i) { bg.tap_w[i] = bg.cls[0].tap_w[i]; bg.tap_off[i] = bg.cls[0].tap_off[i]; }
   if (bg.v4) {                                               // aligned origin: v4sh columns further left
-    bg.bW -= bg.v4sh; bg.cls[0].bW -= bg.v4sh;
-    for (int i = 0; i < css[0].ntaps; ++i) { bg.tap_off[i] += bg.v4sh; bg.cls[0].tap_off[i] += bg.v4sh; }
+    bg.bW -= bg.v4sh;
+    for (int i = 0; i < css[0].ntaps; ++i) bg.tap_off[i] += bg.v4sh;
+    for (int q = 0; q < ncls; ++q) {
+      bg.cls[q].bW -= bg.v4sh;
+      for (int i = 0; i < css[q].ntaps; ++i) bg.cls[q].tap_off[i] += bg.v4sh;
+    }
   }
   if (ncls == 1) bg.ntaps = css[0].ntaps;
   // ~1 workgroup per CU or fewer: 8-wave workgroups with intra-block split-K (small accumulator tiles only)
