@@ -159,10 +159,19 @@ __global__ __launch_bounds__(256) void fold_bwd_d_kernel(const float* __restrict
       for (int s2 = 0; s2 < 9; ++s2) acc[m * 9 + s2] += gm[m] * ws[s2];
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // butterfly over the wave, one exchange STAGE for all 81 sums at a time: 81 independent ds_bpermute in flight per
+  // wait instead of 486 serialised exchange->wait->add steps (that chain was 20 of this kernel's 21 us)
 #pragma unroll
-  for (int k = 0; k < 81; ++k) {
-    const float v = wave_sum(acc[k]);
-    if (lane == 0) part[wave][k] = v;
+  for (int off = 32; off > 0; off >>= 1) {
+    float t[81];
+#pragma unroll
+    for (int k = 0; k < 81; ++k) t[k] = __shfl_xor(acc[k], off, 64);
+#pragma unroll
+    for (int k = 0; k < 81; ++k) acc[k] += t[k];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 81; ++k) part[wave][k] = acc[k];
   }
   __syncthreads();
   if (threadIdx.x < 81) dD[i * 81 + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
