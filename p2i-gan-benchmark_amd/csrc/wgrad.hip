@@ -32,6 +32,7 @@ struct WgradGeom {
   int tap_offq[9];       // tap offsets in the [row][c][eWq] image
   unsigned mg_ewq, mg_pp, x_bytes, dy_bytes;
   int dbg;               // diagnostics only (P2I_WGRAD_DBG): 1 = skip MFMA, 2 = skip DMA after the first tile
+  float* dbias;          // DMA variant, Y4: != null -> the c-block-0 workgroups also sum their dy tiles per channel (bias gradient)
   int x4, x4sh;          // x image filled by 16-B DMA: rows start x4sh columns left of the tap window (16-B aligned)
   unsigned mg_ewq4;
   float* partial;        // != null: workgroup blockIdx.x STORES its partial tile to partial + blockIdx.x * pstride (same
@@ -313,12 +314,24 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
   const int lju = g.ljw - (Y4 ? 2 : 1);                   // log2(units per pixel row)
   const int upr_m = (1 << lju) - 1;
   int k = 0;
+  const bool fuse_bias = Y4 && g.dbias != nullptr && blockIdx.y == 0;   // bias gradient rides on the staged dy tiles
+  float bsum = 0.f;
   if ((int)blockIdx.x < g.ntiles) issue(blockIdx.x, 0);
   for (int tile = blockIdx.x; tile < g.ntiles; tile += g.nsplit, ++k) {
     dma_wait_all();                                     // this wave's share of the tile has landed ...
     __syncthreads();                                    // ... and so has everybody else's; the other buffer is free
     float* cur = smem + (k & 1) * BUFSZ;
     if (tile + g.nsplit < g.ntiles && !(g.dbg & 2)) issue(tile + g.nsplit, ((k + 1) & 1) * BUFSZ);
+    if constexpr (Y4) {
+      if (fuse_bias) {                                      // 64 channels x 8 segments of NPIX/8 pixels; padding pixels are 0
+        const float* yrow = cur + YOFF + (tid >> 3) * PP + (tid & 7) * (NPIX / 8);
+#pragma unroll
+        for (int q = 0; q < NPIX / 8; q += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(yrow + q);
+          bsum += (v.x + v.y) + (v.z + v.w);
+        }
+      }
+    }
     const float* xa = cur + xlane;
     const float* yb = cur + YOFF + ylane;
     auto xoff = [&](int uu) {                            // x-image offset of unit uu of this wave's k-range
@@ -374,6 +387,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
         for (int t = 0; t < NTAP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
       }
     }
+  }
+  if (fuse_bias) {
+    bsum += __shfl_xor(bsum, 1, 64);
+    bsum += __shfl_xor(bsum, 2, 64);
+    bsum += __shfl_xor(bsum, 4, 64);
+    const int oc = o0 + (tid >> 3);
+    if ((tid & 7) == 0 && oc < g.Co) atomicAdd(g.dbias + oc, bsum);
   }
   // combine the KS pixel-range partial sums inside the workgroup (through LDS, 4 taps at a time) so that only
   // one wave per (c tile, o tile) issues the global float atomics: they run at ~1.3 TB/s chip-wide and would
@@ -511,6 +531,7 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
   }
   // ---- DMA-pipelined variant (no act'(y) prologue): [row][c][eWq] / [o][PP] images, double buffered.
   // CB = x channels per block: 64, or 32 when the patch is large (strided convs) or Cin is small.
+  bool bias_fused = false;
   bool use_dma = (y_act == nullptr) && (g.tpg == 9 || g.tpg == 1) && jw >= 8;
   if (use_dma) {
     const bool y4 = (d->Wo % 4 == 0);
@@ -565,6 +586,8 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
         for (int b = 0; b < d->kh; ++b)
           for (int c = 0; c < d->kw; ++c) ga.tap_offq[b * d->kw + c] = b * g.rowblk + c + g.x4sh;
         if (g.x4) ga.bW = g.bW - g.x4sh;
+        ga.dbias = (dbias != nullptr && y4 && a == 0) ? dbias : nullptr;   // one kt slice sums dy (every slice sees all of it)
+        if (ga.dbias) bias_fused = true;
         // slice mode: ns >= 2 partial tiles per output element and a scratch that holds all ns slices of this launch
         const long long slice = (long long)g.tpg * d->Cin * g.CoPad;
         const bool sliced = ns >= 2 && g_wgrad_ws != nullptr && slice * ns <= g_wgrad_ws_floats && slice < (1ll << 31);
@@ -598,6 +621,6 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
     hipLaunchKernelGGL(wgrad_kernel<NPIX>, dim3(nsplit, ncx, nco), dim3(256), lds, s, ga);
     if (int e = launch_status()) return e;
   }
-  if (dbias) return p2i_bias_grad(dy, y_act, act, dbias, d->B, d->Cout, (int64_t)d->To * d->Ho * d->Wo, stream);
+  if (dbias && !bias_fused) return p2i_bias_grad(dy, y_act, act, dbias, d->B, d->Cout, (int64_t)d->To * d->Ho * d->Wo, stream);
   return P2I_OK;
 }
