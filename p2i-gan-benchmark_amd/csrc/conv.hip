@@ -287,8 +287,46 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
   const int nwv = nwrows * V;                        // float4 per chunk
   __syncthreads();                                   // tables visible
 
+  // The per-lane source offsets are the same for every chunk (the chunk rides in the scalar offset): when a thread owns
+  // only a few DMA lanes, keep them in registers so that the issue right after the barrier is not a chain of
+  // ds_read -> wait -> DMA (the MFMAs of the chunk start behind it)
+  constexpr int RW = 8, RP = 4;
+  const int nwq = (((nwv + 63) & ~63) + NTH - 1) / NTH;          // weight DMA instructions of this thread
+  const int npq = g.v4 ? (PT4p + NTH - 1) / NTH : RP + 1;        // patch DMA instructions (16-B mode only)
+  const bool reg_issue = nwq <= RW && npq <= RP;
+  int wv[RW], pv[RP];
+  if (reg_issue) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int f = i * NTH + tid;
+      int voff = -4;
+      if (i < nwq && f < nwv) {
+        const int row = f / V, col4 = f - row * V;
+        const int base = wtab[row];
+        voff = base < 0 ? -4 : base + col4 * 16;
+      }
+      wv[i] = voff;
+    }
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const int e = i * NTH + tid;
+      pv[i] = (i < npq && e < PT4p) ? ptab[e] : -16;
+    }
+  }
   auto issue = [&](int c0, int bufoff) {                 // bufoff: float offset of the target buffer inside smem
     const int w_soff = c0 * g.CmPad * 4;
+    if (reg_issue) {
+      const int p_soff = c0 * chan_bytes, pbo = bufoff + WSZ;
+#pragma unroll
+      for (int i = 0; i < RW; ++i)
+        if (i < nwq && i * NTH + wbase < ((nwv + 63) & ~63))
+          dma_b128(rs_w, smem_la + 4u * (bufoff + (i * NTH + wbase) * 4), wv[i], w_soff);
+#pragma unroll
+      for (int i = 0; i < RP; ++i)
+        if (i < npq && i * NTH + wbase < PT4p)
+          dma_b128(rs_src, smem_la + 4u * (pbo + (i * NTH + wbase) * 4), pv[i], p_soff);
+      return;
+    }
     for (int f0 = 0; f0 < nwv; f0 += NTH) {          // weights: 16 B per lane
       const int f = f0 + tid;
       int voff = -4;
