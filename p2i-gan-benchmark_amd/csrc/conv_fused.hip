@@ -117,8 +117,44 @@ __global__ __launch_bounds__(256) void patch_gemm_fused_kernel(const PatchGeom g
   const int nwv = nwrows * V;
   __syncthreads();
 
+  // few DMA lanes per thread: offsets in registers, no LDS lookup chain in the issue (see patch_gemm_dma_kernel)
+  constexpr int RW = 12, RP = 4;
+  const int nwq = (((nwv + 63) & ~63) + 255) / 256;
+  const int npq = g.v4 ? (PT4p + 255) / 256 : RP + 1;
+  const bool reg_issue = nwq <= RW && npq <= RP;
+  int wv[RW], pv[RP];
+  if (reg_issue) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int f = i * 256 + tid;
+      int voff = -4;
+      if (i < nwq && f < nwv) {
+        const int row = f / V, col4 = f - row * V;
+        const int base = wtab[row];
+        voff = base < 0 ? -4 : base + col4 * 16;
+      }
+      wv[i] = voff;
+    }
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const int e = i * 256 + tid;
+      pv[i] = (i < npq && e < PT4p) ? ptab[e] : -16;
+    }
+  }
   auto issue = [&](int c0, int bufoff) {
     const int w_soff = c0 * g.CmPad * 4;
+    if (reg_issue) {
+      const int p_soff = c0 * chan_bytes, pbo = bufoff + WSZ;
+#pragma unroll
+      for (int i = 0; i < RW; ++i)
+        if (i < nwq && i * 256 + wbase < ((nwv + 63) & ~63))
+          dma_b128(rs_w, smem_la + 4u * (bufoff + (i * 256 + wbase) * 4), wv[i], w_soff);
+#pragma unroll
+      for (int i = 0; i < RP; ++i)
+        if (i < npq && i * 256 + wbase < PT4p)
+          dma_b128(rs_src, smem_la + 4u * (pbo + (i * 256 + wbase) * 4), pv[i], p_soff);
+      return;
+    }
     for (int f0 = 0; f0 < nwv; f0 += 256) {
       const int f = f0 + tid;
       int voff = -4;
