@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
   // The per-lane source offsets are the same for every chunk (the chunk rides in the scalar offset): when a thread owns
   // only a few DMA lanes, keep them in registers so that the issue right after the barrier is not a chain of
   // ds_read -> wait -> DMA (the MFMAs of the chunk start behind it)
-  constexpr int RW = 8, RP = 4;
+  constexpr int RW = 10, RP = 4;                                 // 10: 128-channel tiles at CK = 8 (9 taps) still qualify
   const int nwq = (((nwv + 63) & ~63) + NTH - 1) / NTH;          // weight DMA instructions of this thread
   const int npq = g.v4 ? (PT4p + NTH - 1) / NTH : RP + 1;        // patch DMA instructions (16-B mode only)
   const bool reg_issue = nwq <= RW && npq <= RP;
