@@ -126,6 +126,11 @@ int p2i_weight_unpack_grad(const float* dwp_f, int O, int I, int ntaps, const fl
 int p2i_spectral_norm(const float* w, int O, int K, float* u, float* v, int training, float* sigma,
                       float* scratch, void* stream);
 
+/* The same power iteration for n <= 16 layers at once (blockIdx.z = layer): 4 launches for the whole discriminator instead
+ * of 4-5 per layer.  Arrays of n HOST entries holding device pointers / sizes; scratch[i] >= O[i] + K[i] + 4 floats. */
+int p2i_spectral_norm_batched(const float* const* w, const int* O, const int* K, float* const* u, float* const* v,
+                              int training, float* const* sigma, float* const* scratch, int n, void* stream);
+
 /* ------------------------------------------------------------------ generator glue
  * AttentionBlock x2 (layer.py:296-304, 318-322): per pixel relu(x + x*(Wx+b)) over the T=16 vector. */
 int p2i_attn_fwd(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,

@@ -256,6 +256,72 @@ __global__ void sn_normalize_kernel(const float* __restrict__ in, int n, float* 
     if (threadIdx.x == 0) *sigma = dot;
   }
 }
+// ---- the same power iteration for ALL spectral-norm layers of a network in 4 launches (blockIdx.z = layer) instead of
+//      4-5 launches per layer: these kernels are launch-latency bound (4-8 us each, 120 of them per training step)
+constexpr int SN_MAX_LAYERS = 16;
+struct SnBatch {
+  const float* w[SN_MAX_LAYERS];
+  float* u[SN_MAX_LAYERS];
+  float* v[SN_MAX_LAYERS];
+  float* sigma[SN_MAX_LAYERS];
+  float* scratch[SN_MAX_LAYERS];     // >= O + K + 4 floats each: t[K] then sv[O]
+  int O[SN_MAX_LAYERS], K[SN_MAX_LAYERS];
+  int n;
+};
+// t[k] = sum_o W[o][k] u[o]: block = 64 columns x 4 row groups, each group strides over all rows (no atomics, no memset)
+__global__ __launch_bounds__(256) void sn_wtu_batched_kernel(const SnBatch b) {
+  __shared__ float part[4][64];
+  const int L = blockIdx.z, O = b.O[L], K = b.K[L];
+  if ((int)blockIdx.x * 64 >= K) return;
+  const float* w = b.w[L];
+  const float* u = b.u[L];
+  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6, k = blockIdx.x * 64 + col;
+  float acc = 0.f;
+  if (k < K)
+    for (int o = rg; o < O; o += 4) acc += w[(size_t)o * K + k] * u[o];
+  part[rg][col] = acc;
+  __syncthreads();
+  if (rg == 0 && k < K) b.scratch[L][k] = part[0][col] + part[1][col] + part[2][col] + part[3][col];
+}
+__global__ void sn_wv_batched_kernel(const SnBatch b) {
+  const int L = blockIdx.z, O = b.O[L], K = b.K[L];
+  const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= O) return;
+  const float* w = b.w[L];
+  const float* v = b.v[L];
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += w[(size_t)o * K + k] * v[k];
+  acc = wave_sum(acc);
+  if (lane == 0) b.scratch[L][K + o] = acc;
+}
+// phase 0: v = normalize(t);  phase 1: u = normalize(sv), sigma = u . sv;  phase 2 (eval): sigma = u . sv
+__global__ void sn_finish_batched_kernel(const SnBatch b, int phase) {
+  __shared__ float red[16];
+  const int L = blockIdx.z, O = b.O[L], K = b.K[L];
+  const float* in = phase == 0 ? b.scratch[L] : b.scratch[L] + K;
+  const int n = phase == 0 ? K : O;
+  if (phase == 2) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += b.u[L][i] * in[i];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) *b.sigma[L] = acc;
+    return;
+  }
+  float* out = phase == 0 ? b.v[L] : b.u[L];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += in[i] * in[i];
+  const float nrm = fmaxf(sqrtf(block_sum(acc, red)), 1e-12f);
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float o = in[i] / nrm;
+    out[i] = o;
+    dot += o * in[i];
+  }
+  if (phase == 1) {
+    dot = block_sum(dot, red);
+    if (threadIdx.x == 0) *b.sigma[L] = dot;
+  }
+}
 __global__ void sn_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float* out) {
   __shared__ float red[16];
   float acc = 0.f;
@@ -343,6 +409,32 @@ extern "C" int p2i_spectral_norm(const float* w, int O, int K, float* u, float* 
   } else {
     hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(O, 4)), dim3(256), 0, s, w, v, O, K, sv);
     hipLaunchKernelGGL(sn_dot_kernel, dim3(1), dim3(1024), 0, s, u, sv, O, sigma);
+  }
+  return launch_status();
+}
+
+extern "C" int p2i_spectral_norm_batched(const float* const* w, const int* O, const int* K, float* const* u, float* const* v,
+                                         int training, float* const* sigma, float* const* scratch, int n, void* stream) {
+  P2I_REQUIRE(w && O && K && u && v && sigma && scratch && n >= 1 && n <= SN_MAX_LAYERS, "1..%d layers", SN_MAX_LAYERS);
+  SnBatch b;
+  int maxO = 0, maxK = 0;
+  for (int i = 0; i < SN_MAX_LAYERS; ++i) {
+    const int j = i < n ? i : 0;
+    P2I_REQUIRE(w[j] && u[j] && v[j] && sigma[j] && scratch[j] && O[j] > 0 && K[j] > 0, "bad spectral-norm layer %d", j);
+    b.w[i] = w[j]; b.u[i] = u[j]; b.v[i] = v[j]; b.sigma[i] = sigma[j]; b.scratch[i] = scratch[j]; b.O[i] = O[j]; b.K[i] = K[j];
+    if (O[j] > maxO) maxO = O[j];
+    if (K[j] > maxK) maxK = K[j];
+  }
+  b.n = n;
+  hipStream_t s = (hipStream_t)stream;
+  if (training) {
+    hipLaunchKernelGGL(sn_wtu_batched_kernel, dim3(ceil_div(maxK, 64), 1, n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(sn_finish_batched_kernel, dim3(1, 1, n), dim3(1024), 0, s, b, 0);
+    hipLaunchKernelGGL(sn_wv_batched_kernel, dim3(ceil_div(maxO, 4), 1, n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(sn_finish_batched_kernel, dim3(1, 1, n), dim3(1024), 0, s, b, 1);
+  } else {
+    hipLaunchKernelGGL(sn_wv_batched_kernel, dim3(ceil_div(maxO, 4), 1, n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(sn_finish_batched_kernel, dim3(1, 1, n), dim3(1024), 0, s, b, 2);
   }
   return launch_status();
 }

@@ -422,11 +422,16 @@ class _DiscriminatorFn(torch.autograd.Function):
         need_p = net._grad_on and any(ctx.needs_input_grad[2:])
         training = net.training
 
+        # power iteration of all ten layers in 4 launches (parameters only; u, v are updated in place as torch does)
+        sig_all = ops.spectral_norm_batched([m.weight_orig for m in l2 + l3], [m.weight_u for m in l2 + l3],
+                                            [m.weight_v for m in l2 + l3], training)
+        sig_of = {id(m): sg for m, sg in zip(l2 + l3, sig_all)}
+
         def branch(layers, specs, inp):
             recs, cur = [], inp
             for n, (m, spec) in enumerate(zip(layers, specs)):
                 wo = m.weight_orig
-                sigma = ops.spectral_norm(wo, m.weight_u, m.weight_v, training)
+                sigma = sig_of[id(m)]
                 wflat = wo.reshape(wo.shape[0], wo.shape[1], -1)
                 wp_f, wp_d = ops.weight_pack(wflat, sigma, need_d=(need_x or need_p))
                 act = ACT_LEAKY if n < 4 else ACT_NONE

@@ -347,6 +347,36 @@ def spectral_norm(w, u, v, training: bool):
     return sigma
 
 
+def spectral_norm_batched(ws, us, vs, training: bool):
+    """spectral_norm() for a list of layers in 4 launches (these kernels are launch-latency bound).  Returns the list of
+    sigma tensors (views of one buffer)."""
+    import ctypes
+    lib = _hip.load()
+    n = len(ws)
+    if not (1 <= n <= 16 and len(us) == n and len(vs) == n):
+        raise RuntimeError("spectral_norm_batched: 1..16 layers")
+    Os = [w.shape[0] for w in ws]
+    Ks = [w.numel() // w.shape[0] for w in ws]
+    for w, u, v, O, K in zip(ws, us, vs, Os, Ks):
+        if u.numel() != O or v.numel() != K:
+            raise RuntimeError("spectral_norm_batched: u/v size mismatch")
+        _chk(w, u, v)
+    dev = ws[0].device
+    sig = torch.empty(n, device=dev, dtype=torch.float32)
+    offs = [0]
+    for O, K in zip(Os, Ks):
+        offs.append(offs[-1] + (O + K + 4 + 3) // 4 * 4)
+    scratch = torch.empty(offs[-1], device=dev, dtype=torch.float32)
+    arr_p = ctypes.c_void_p * n
+    arr_i = ctypes.c_int * n
+    wp, up, vp = arr_p(*[w.data_ptr() for w in ws]), arr_p(*[u.data_ptr() for u in us]), arr_p(*[v.data_ptr() for v in vs])
+    sp = arr_p(*[sig.data_ptr() + 4 * i for i in range(n)])
+    cp = arr_p(*[scratch.data_ptr() + 4 * o for o in offs[:-1]])
+    _hip.check(lib.p2i_spectral_norm_batched(wp, arr_i(*Os), arr_i(*Ks), up, vp, int(training), sp, cp, n, _stream()),
+               "p2i_spectral_norm_batched")
+    return [sig[i:i + 1] for i in range(n)]
+
+
 # --------------------------------------------------------------------------- generator glue
 def attn_fwd(x, w0, b0, w1, b1):
     lib = _hip.load()

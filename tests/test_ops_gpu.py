@@ -404,3 +404,18 @@ def test_wgrad_slices_are_bit_reproducible_and_match_atomics(ops):
             ops.WGRAD_SLICES = old
         assert torch.equal(a, b)
         assert rel_err(a.cpu().numpy(), c.cpu().numpy()) < 1e-5
+
+
+def test_spectral_norm_batched_matches_per_layer(ops):
+    """p2i_spectral_norm_batched (all layers in 4 launches) == p2i_spectral_norm layer by layer, training and eval."""
+    shapes = [(64, 16, 3, 3), (128, 64, 3, 3), (32, 1, 3, 3, 3), (1, 128, 1, 1, 1), (256, 256, 3, 3)]
+    ws = [_rand(*sh, seed=10 + i, scale=0.1).cuda() for i, sh in enumerate(shapes)]
+    for training in (True, False):
+        us = [F.normalize(_rand(w.shape[0], seed=20 + i), dim=0).cuda() for i, w in enumerate(ws)]
+        vs = [F.normalize(_rand(w.numel() // w.shape[0], seed=30 + i), dim=0).cuda() for i, w in enumerate(ws)]
+        u1, v1 = [u.clone() for u in us], [v.clone() for v in vs]
+        s1 = [ops.spectral_norm(w, u, v, training) for w, u, v in zip(ws, u1, v1)]
+        sb = ops.spectral_norm_batched(ws, us, vs, training)
+        for i in range(len(ws)):
+            assert abs(float(sb[i]) - float(s1[i])) <= 1e-5 * abs(float(s1[i])), (i, training)
+            assert rel_err(us[i].cpu().numpy(), u1[i].cpu().numpy()) < 1e-5 and rel_err(vs[i].cpu().numpy(), v1[i].cpu().numpy()) < 1e-5
