@@ -108,6 +108,14 @@ int p2i_doconv_fold_fwd(const float* W, const float* D, const float* D_diag, int
 int p2i_doconv_fold_bwd(const float* dwp_f, const float* W, const float* D, const float* D_diag,
                         int O, int I, int groups, int ksz, float* dW, float* dD, void* stream);
 
+/* The same fold / fold backward for n <= 16 layers of ONE shape (3x3, groups 1, O and I multiples of 32: the generator's
+ * residual stack has 8 per level) in one / two launches; arrays of n HOST entries holding device pointers. */
+int p2i_doconv_fold_fwd_batched(const float* const* W, const float* const* D, const float* const* D_diag, int n, int O, int I,
+                                float* const* wp_f, float* const* wp_d, void* stream);
+int p2i_doconv_fold_bwd_batched(const float* const* dwp_f, const float* const* W, const float* const* D,
+                                const float* const* D_diag, int n, int O, int I, float* const* dW, float* const* dD,
+                                void* stream);
+
 /* Plain (O, I, ntaps) weights <-> packed.  scale_ptr (device scalar, may be NULL) divides: used
  * for the spectral-norm weight = weight_orig / sigma. */
 int p2i_weight_pack(const float* w, int O, int I, int ntaps, const float* inv_div_ptr,

@@ -19,8 +19,19 @@ __device__ __forceinline__ int pad32(int v) { return (v + 31) & ~31; }
 // ---- DO-Conv fold.  One thread per flat pair q = o'*I + i of the (O/g, I, 9) view; a block owns a
 // 16 (o') x 16 (i) tile so that BOTH packed layouts are written in 64-B runs (wp_f: o contiguous,
 // wp_d: cin contiguous) via an LDS transpose.  groups == 1 only; grouped / 1x1 layers use the simple kernel.
-__global__ __launch_bounds__(256) void fold_fwd_tile_kernel(const float* __restrict__ W, const float* __restrict__ D,
-                                                           const float* __restrict__ Dd, int O, int I, float* wp_f, float* wp_d) {
+constexpr int FOLD_MAX_LAYERS = 16;
+// same-shape layers of one launch (blockIdx.z = layer): the fold kernels are launch-latency bound (8-12 us each)
+struct FoldBatch {
+  const float* W[FOLD_MAX_LAYERS];
+  const float* D[FOLD_MAX_LAYERS];
+  const float* Dd[FOLD_MAX_LAYERS];
+  float* a[FOLD_MAX_LAYERS];          // fwd: wp_f   bwd: dW
+  float* b[FOLD_MAX_LAYERS];          // fwd: wp_d   bwd: dD
+  const float* g[FOLD_MAX_LAYERS];    // bwd: packed weight gradient
+};
+
+__device__ __forceinline__ void fold_fwd_tile_body(const float* __restrict__ W, const float* __restrict__ D,
+                                                   const float* __restrict__ Dd, int O, int I, float* wp_f, float* wp_d) {
   __shared__ float tile[9][16][17];
   const int ti = threadIdx.x & 15, to = threadIdx.x >> 4;     // thread computes (o' = o0+to, i = i0+ti): W reads 36-B runs
   const int o0 = blockIdx.y * 16, i0 = blockIdx.x * 16;
@@ -49,6 +60,14 @@ __global__ __launch_bounds__(256) void fold_fwd_tile_kernel(const float* __restr
     // wp_d[m][o][i]: lanes along i
     if (wp_d && o0 + b < O && i0 + a < I) wp_d[((size_t)m * O + o0 + b) * I + i0 + a] = tile[m][b][a];
   }
+}
+__global__ __launch_bounds__(256) void fold_fwd_tile_kernel(const float* __restrict__ W, const float* __restrict__ D,
+                                                           const float* __restrict__ Dd, int O, int I, float* wp_f, float* wp_d) {
+  fold_fwd_tile_body(W, D, Dd, O, I, wp_f, wp_d);
+}
+__global__ __launch_bounds__(256) void fold_fwd_tile_batched_kernel(const FoldBatch fb, int O, int I) {
+  const int L = blockIdx.z;
+  fold_fwd_tile_body(fb.W[L], fb.D[L], fb.Dd[L], O, I, fb.a[L], fb.b[L]);
 }
 
 __global__ void fold_fwd_kernel(const float* __restrict__ W, const float* __restrict__ D, const float* __restrict__ Dd,
@@ -84,8 +103,8 @@ __global__ void fold_fwd_kernel(const float* __restrict__ W, const float* __rest
 }
 
 // dW[o'][i][s] = sum_m dDoW[o',i,m] (D+Dd)[i][m][s] for groups == 1: dDoW tile gathered with o-contiguous reads
-__global__ __launch_bounds__(256) void fold_bwd_w_tile_kernel(const float* __restrict__ dwp, const float* __restrict__ D,
-                                                             const float* __restrict__ Dd, int O, int I, float* dW) {
+__device__ __forceinline__ void fold_bwd_w_tile_body(const float* __restrict__ dwp, const float* __restrict__ D,
+                                                     const float* __restrict__ Dd, int O, int I, float* dW) {
   __shared__ float tile[9][16][17];
   const int o0 = blockIdx.y * 16, i0 = blockIdx.x * 16;
   const int a = threadIdx.x & 15, b = threadIdx.x >> 4;
@@ -109,6 +128,14 @@ __global__ __launch_bounds__(256) void fold_bwd_w_tile_kernel(const float* __res
     for (int m = 0; m < 9; ++m) acc += g[m] * (d[m * 9 + s2] + dd[m * 9 + s2]);
     out[s2] = acc;
   }
+}
+__global__ __launch_bounds__(256) void fold_bwd_w_tile_kernel(const float* __restrict__ dwp, const float* __restrict__ D,
+                                                             const float* __restrict__ Dd, int O, int I, float* dW) {
+  fold_bwd_w_tile_body(dwp, D, Dd, O, I, dW);
+}
+__global__ __launch_bounds__(256) void fold_bwd_w_tile_batched_kernel(const FoldBatch fb, int O, int I) {
+  const int L = blockIdx.z;
+  fold_bwd_w_tile_body(fb.g[L], fb.D[L], fb.Dd[L], O, I, fb.a[L]);
 }
 
 // dW (O/g, I, 9) from packed dDoW: dW[q][s] = sum_m dDoW[q][m] * (D+Dd)[i][m][s]
@@ -138,8 +165,8 @@ __global__ void fold_bwd_w_kernel(const float* __restrict__ dwp, const float* __
 
 // dD[i][m][s] = sum_{o'} dDoW[o',i,m] * W[o',i,s]; block per i, threads stride over o' (coalesced dDoW reads),
 // 81 register accumulators per thread, wave shuffle + LDS combine
-__global__ __launch_bounds__(256) void fold_bwd_d_kernel(const float* __restrict__ dwp, const float* __restrict__ W, int O, int I,
-                                                        int groups, float* dD) {
+__device__ __forceinline__ void fold_bwd_d_body(const float* __restrict__ dwp, const float* __restrict__ W, int O, int I,
+                                                int groups, float* dD) {
   __shared__ float part[4][81];
   const int i = blockIdx.x;
   const int Ig = I / groups, Og = O / groups, Opad = pad32(O);
@@ -175,6 +202,14 @@ __global__ __launch_bounds__(256) void fold_bwd_d_kernel(const float* __restrict
   }
   __syncthreads();
   if (threadIdx.x < 81) dD[i * 81 + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void fold_bwd_d_kernel(const float* __restrict__ dwp, const float* __restrict__ W, int O, int I,
+                                                        int groups, float* dD) {
+  fold_bwd_d_body(dwp, W, O, I, groups, dD);
+}
+__global__ __launch_bounds__(256) void fold_bwd_d_batched_kernel(const FoldBatch fb, int O, int I) {
+  const int L = blockIdx.z;
+  fold_bwd_d_body(fb.g[L], fb.W[L], O, I, 1, fb.b[L]);
 }
 
 // ---- plain (O, I, NT) <-> packed
@@ -436,5 +471,34 @@ extern "C" int p2i_spectral_norm_batched(const float* const* w, const int* O, co
     hipLaunchKernelGGL(sn_wv_batched_kernel, dim3(ceil_div(maxO, 4), 1, n), dim3(256), 0, s, b);
     hipLaunchKernelGGL(sn_finish_batched_kernel, dim3(1, 1, n), dim3(1024), 0, s, b, 2);
   }
+  return launch_status();
+}
+
+// n <= 16 same-shape 3x3 DO-Conv layers (groups 1, O and I multiples of 32: the generator's residual stack) in ONE launch
+extern "C" int p2i_doconv_fold_fwd_batched(const float* const* W, const float* const* D, const float* const* D_diag, int n, int O, int I,
+                                           float* const* wp_f, float* const* wp_d, void* stream) {
+  P2I_REQUIRE(W && D && D_diag && wp_f && n >= 1 && n <= FOLD_MAX_LAYERS, "1..%d layers", FOLD_MAX_LAYERS);
+  P2I_REQUIRE(O > 0 && I > 0 && O % 32 == 0 && I % 32 == 0, "batched fold needs O, I multiples of 32");
+  FoldBatch fb{};
+  for (int i = 0; i < n; ++i) {
+    P2I_REQUIRE(W[i] && D[i] && D_diag[i] && wp_f[i], "null pointer (layer %d)", i);
+    fb.W[i] = W[i]; fb.D[i] = D[i]; fb.Dd[i] = D_diag[i]; fb.a[i] = wp_f[i]; fb.b[i] = wp_d ? wp_d[i] : nullptr;
+  }
+  hipLaunchKernelGGL(fold_fwd_tile_batched_kernel, dim3(ceil_div(I, 16), ceil_div(O, 16), n), dim3(256), 0, (hipStream_t)stream, fb, O, I);
+  return launch_status();
+}
+extern "C" int p2i_doconv_fold_bwd_batched(const float* const* dwp_f, const float* const* W, const float* const* D,
+                                           const float* const* D_diag, int n, int O, int I, float* const* dW, float* const* dD,
+                                           void* stream) {
+  P2I_REQUIRE(dwp_f && W && D && D_diag && dW && dD && n >= 1 && n <= FOLD_MAX_LAYERS, "1..%d layers", FOLD_MAX_LAYERS);
+  P2I_REQUIRE(O > 0 && I > 0 && O % 32 == 0 && I % 32 == 0, "batched fold needs O, I multiples of 32");
+  FoldBatch fb{};
+  for (int i = 0; i < n; ++i) {
+    P2I_REQUIRE(dwp_f[i] && W[i] && D[i] && D_diag[i] && dW[i] && dD[i], "null pointer (layer %d)", i);
+    fb.g[i] = dwp_f[i]; fb.W[i] = W[i]; fb.D[i] = D[i]; fb.Dd[i] = D_diag[i]; fb.a[i] = dW[i]; fb.b[i] = dD[i];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(fold_bwd_w_tile_batched_kernel, dim3(ceil_div(I, 16), ceil_div(O, 16), n), dim3(256), 0, s, fb, O, I);
+  hipLaunchKernelGGL(fold_bwd_d_batched_kernel, dim3(I, 1, n), dim3(256), 0, s, fb, O, I);
   return launch_status();
 }

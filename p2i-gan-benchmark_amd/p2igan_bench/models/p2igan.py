@@ -213,10 +213,15 @@ class _GeneratorFn(torch.autograd.Function):
             ch = BASE_CH << lvl
             spec = _spec2d(ch, ch, 3)
             rec = []
+            folded = {}
+            if need_grad:                                # the level's 2*num_res same-shape folds in ONE launch
+                convs = [_doconv_of(m) for rb in net.Decoder[lvl].layers for m in (rb.main[0], rb.main[1])]
+                for cv, wp in zip(convs, ops.doconv_fold_batched([cv.tensors() for cv in convs], ch, ch, need_d=True)):
+                    folded[id(cv)] = wp
             for rb in net.Decoder[lvl].layers:
                 c1, c2 = _doconv_of(rb.main[0]), _doconv_of(rb.main[1])
-                w1 = fold(c1, ch, ch, 1, 3)
-                w2 = fold(c2, ch, ch, 1, 3)
+                w1 = folded[id(c1)] if need_grad else fold(c1, ch, ch, 1, 3)
+                w2 = folded[id(c2)] if need_grad else fold(c2, ch, ch, 1, 3)
                 y1 = ops.conv_fwd(spec, hcur, w1[0], act=ACT_RELU)
                 hn = ops.conv_fwd(spec, y1, w2[0], residual=hcur)
                 rec.append((hcur, y1, w1[1], w2[1]))
@@ -270,14 +275,18 @@ class _GeneratorFn(torch.autograd.Function):
             ch = BASE_CH << lvl
             spec = _spec2d(ch, ch, 3)
             blocks = net.Decoder[lvl].layers
+            pend = []                                    # (packed weight gradient, layer): folded back in two launches per level
             for rb, (hin, y1, w1d, w2d) in zip(reversed(list(blocks)), reversed(S["rec"][lvl])):
                 c1, c2 = _doconv_of(rb.main[0]), _doconv_of(rb.main[1])
                 dwp2, _ = ops.conv_wgrad(spec, y1, dh, arena=arena)
-                grads[id(c2.W)], grads[id(c2.D)] = ops.doconv_fold_bwd(dwp2, *c2.tensors(), ch, ch, 1, 3)
+                pend.append((dwp2, c2))
                 dy1 = ops.conv_dgrad(spec, dh, w2d, tuple(y1.shape), mask_y=y1, mask_act=ACT_RELU)   # * relu'(y1) fused
                 dwp1, _ = ops.conv_wgrad(spec, hin, dy1, arena=arena)
-                grads[id(c1.W)], grads[id(c1.D)] = ops.doconv_fold_bwd(dwp1, *c1.tensors(), ch, ch, 1, 3)
+                pend.append((dwp1, c1))
                 dh = ops.conv_dgrad(spec, dy1, w1d, tuple(hin.shape), add=dh)                     # + skip path
+            dWs, dDs = ops.doconv_fold_bwd_batched([g_ for g_, _ in pend], [cv.tensors() for _, cv in pend], ch, ch)
+            for (_, cv), dW_, dD_ in zip(pend, dWs, dDs):
+                grads[id(cv.W)], grads[id(cv.D)] = dW_, dD_
             return dh
 
         def uppos_bwd(i, dr):

@@ -306,6 +306,49 @@ def doconv_fold_bwd(dwp_f, W, D, D_diag, out_ch, in_ch, groups, ksz):
     return dW, dD
 
 
+def _ptr_array(ts):
+    import ctypes
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def doconv_fold_batched(layers, out_ch, in_ch, need_d=True):
+    """doconv_fold for a list of same-shape 3x3 layers [(W, D, D_diag), ...] (groups 1) in ONE launch.
+    Returns [(wp_f, wp_d), ...] (views of two stacked buffers)."""
+    lib = _hip.load()
+    n = len(layers)
+    for W, D, Dd in layers:
+        if tuple(W.shape) != (out_ch, in_ch, 9) or tuple(D.shape) != (in_ch, 9, 9) or tuple(Dd.shape) != (in_ch, 9, 9):
+            raise RuntimeError("doconv_fold_batched: shape mismatch")
+        _chk(W, D, Dd)
+    dev = layers[0][0].device
+    wf = torch.empty((n, 9, in_ch, out_ch), device=dev, dtype=torch.float32)
+    wd = torch.empty((n, 9, out_ch, in_ch), device=dev, dtype=torch.float32) if need_d else None
+    _hip.check(lib.p2i_doconv_fold_fwd_batched(_ptr_array([l[0] for l in layers]), _ptr_array([l[1] for l in layers]),
+                                               _ptr_array([l[2] for l in layers]), n, out_ch, in_ch, _ptr_array([wf[i] for i in range(n)]),
+                                               _ptr_array([wd[i] for i in range(n)]) if need_d else None, _stream()),
+               "p2i_doconv_fold_fwd_batched")
+    return [(wf[i], wd[i] if need_d else None) for i in range(n)]
+
+
+def doconv_fold_bwd_batched(dwps, layers, out_ch, in_ch):
+    """doconv_fold_bwd for same-shape layers in TWO launches.  Returns ([dW...], [dD...])."""
+    lib = _hip.load()
+    n = len(layers)
+    if len(dwps) != n:
+        raise RuntimeError("doconv_fold_bwd_batched: list length mismatch")
+    for g in dwps:
+        if tuple(g.shape) != (9, in_ch, out_ch):
+            raise RuntimeError("doconv_fold_bwd_batched: dwp shape mismatch")
+        _chk(g)
+    dev = dwps[0].device
+    dW = torch.empty((n, out_ch, in_ch, 9), device=dev, dtype=torch.float32)
+    dD = torch.empty((n, in_ch, 9, 9), device=dev, dtype=torch.float32)
+    _hip.check(lib.p2i_doconv_fold_bwd_batched(_ptr_array(dwps), _ptr_array([l[0] for l in layers]), _ptr_array([l[1] for l in layers]),
+                                               _ptr_array([l[2] for l in layers]), n, out_ch, in_ch, _ptr_array([dW[i] for i in range(n)]),
+                                               _ptr_array([dD[i] for i in range(n)]), _stream()), "p2i_doconv_fold_bwd_batched")
+    return [dW[i] for i in range(n)], [dD[i] for i in range(n)]
+
+
 def weight_pack(w, sigma=None, need_f=True, need_d=True):
     """w (O, I, *k) -> packed wp_f / wp_d, optionally divided by the device scalar sigma."""
     lib = _hip.load()

@@ -419,3 +419,23 @@ def test_spectral_norm_batched_matches_per_layer(ops):
         for i in range(len(ws)):
             assert abs(float(sb[i]) - float(s1[i])) <= 1e-5 * abs(float(s1[i])), (i, training)
             assert rel_err(us[i].cpu().numpy(), u1[i].cpu().numpy()) < 1e-5 and rel_err(vs[i].cpu().numpy(), v1[i].cpu().numpy()) < 1e-5
+
+
+def test_doconv_fold_batched_matches_per_layer(ops):
+    """p2i_doconv_fold_{fwd,bwd}_batched (a level's same-shape layers in one / two launches) == the per-layer calls."""
+    O = I = 64
+    layers = []
+    for i in range(5):
+        W = _rand(O, I, 9, seed=40 + i, scale=0.2).cuda()
+        D = _rand(I, 9, 9, seed=50 + i, scale=0.05).cuda()
+        Dd = torch.eye(9).reshape(1, 9, 9).repeat(I, 1, 1).cuda()
+        layers.append((W, D, Dd))
+    one = [ops.doconv_fold(W, D, Dd, O, I, 1, 3) for W, D, Dd in layers]
+    bat = ops.doconv_fold_batched(layers, O, I, need_d=True)
+    for (f1, d1), (f2, d2) in zip(one, bat):
+        assert torch.equal(f1, f2) and torch.equal(d1, d2)
+    dwps = [_rand(9, I, O, seed=60 + i).cuda() for i in range(5)]
+    ref = [ops.doconv_fold_bwd(g, W, D, Dd, O, I, 1, 3) for g, (W, D, Dd) in zip(dwps, layers)]
+    dWs, dDs = ops.doconv_fold_bwd_batched(dwps, layers, O, I)
+    for (rW, rD), dW, dD in zip(ref, dWs, dDs):
+        assert torch.equal(rW, dW) and rel_err(dD.cpu().numpy(), rD.cpu().numpy()) < 1e-6
