@@ -137,7 +137,9 @@ int p2i_spectral_norm(const float* w, int O, int K, float* u, float* v, int trai
 /* The same power iteration for n <= 16 layers at once (blockIdx.z = layer): 4 launches for the whole discriminator instead
  * of 4-5 per layer.  Arrays of n HOST entries holding device pointers / sizes; scratch[i] >= O[i] + K[i] + 4 floats. */
 int p2i_spectral_norm_batched(const float* const* w, const int* O, const int* K, float* const* u, float* const* v,
-                              int training, float* const* sigma, float* const* scratch, int n, void* stream);
+                              int training, float* const* sigma, float* const* scratch, float* const* u_snap,
+                              float* const* v_snap, int n, void* stream);   /* u_snap / v_snap (may be NULL): copies of the
+                              updated u, v for the backward pass (training only) */
 
 /* ------------------------------------------------------------------ generator glue
  * AttentionBlock x2 (layer.py:296-304, 318-322): per pixel relu(x + x*(Wx+b)) over the T=16 vector. */

@@ -300,6 +300,8 @@ struct SnBatch {
   float* v[SN_MAX_LAYERS];
   float* sigma[SN_MAX_LAYERS];
   float* scratch[SN_MAX_LAYERS];     // >= O + K + 4 floats each: t[K] then sv[O]
+  float* usnap[SN_MAX_LAYERS];       // optional copies of the UPDATED u / v (what backward needs; the next forward
+  float* vsnap[SN_MAX_LAYERS];       // call overwrites u, v in place)
   int O[SN_MAX_LAYERS], K[SN_MAX_LAYERS];
   int n;
 };
@@ -343,6 +345,7 @@ __global__ void sn_finish_batched_kernel(const SnBatch b, int phase) {
     return;
   }
   float* out = phase == 0 ? b.v[L] : b.u[L];
+  float* snap = phase == 0 ? b.vsnap[L] : b.usnap[L];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) acc += in[i] * in[i];
   const float nrm = fmaxf(sqrtf(block_sum(acc, red)), 1e-12f);
@@ -350,6 +353,7 @@ __global__ void sn_finish_batched_kernel(const SnBatch b, int phase) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const float o = in[i] / nrm;
     out[i] = o;
+    if (snap) snap[i] = o;
     dot += o * in[i];
   }
   if (phase == 1) {
@@ -449,7 +453,8 @@ extern "C" int p2i_spectral_norm(const float* w, int O, int K, float* u, float* 
 }
 
 extern "C" int p2i_spectral_norm_batched(const float* const* w, const int* O, const int* K, float* const* u, float* const* v,
-                                         int training, float* const* sigma, float* const* scratch, int n, void* stream) {
+                                         int training, float* const* sigma, float* const* scratch, float* const* u_snap,
+                                         float* const* v_snap, int n, void* stream) {
   P2I_REQUIRE(w && O && K && u && v && sigma && scratch && n >= 1 && n <= SN_MAX_LAYERS, "1..%d layers", SN_MAX_LAYERS);
   SnBatch b;
   int maxO = 0, maxK = 0;
@@ -457,6 +462,7 @@ extern "C" int p2i_spectral_norm_batched(const float* const* w, const int* O, co
     const int j = i < n ? i : 0;
     P2I_REQUIRE(w[j] && u[j] && v[j] && sigma[j] && scratch[j] && O[j] > 0 && K[j] > 0, "bad spectral-norm layer %d", j);
     b.w[i] = w[j]; b.u[i] = u[j]; b.v[i] = v[j]; b.sigma[i] = sigma[j]; b.scratch[i] = scratch[j]; b.O[i] = O[j]; b.K[i] = K[j];
+    b.usnap[i] = (training && u_snap) ? u_snap[j] : nullptr; b.vsnap[i] = (training && v_snap) ? v_snap[j] : nullptr;
     if (O[j] > maxO) maxO = O[j];
     if (K[j] > maxK) maxK = K[j];
   }

@@ -43,7 +43,7 @@ SIGNATURES = {
     "p2i_weight_pack": [_P, _I, _I, _I, _P, _P, _P, _P],
     "p2i_weight_unpack_grad": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "p2i_spectral_norm": [_P, _I, _I, _P, _P, _I, _P, _P, _P],
-    "p2i_spectral_norm_batched": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    "p2i_spectral_norm_batched": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "p2i_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "p2i_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "p2i_idw_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],

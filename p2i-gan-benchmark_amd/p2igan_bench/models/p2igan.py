@@ -432,9 +432,11 @@ class _DiscriminatorFn(torch.autograd.Function):
         training = net.training
 
         # power iteration of all ten layers in 4 launches (parameters only; u, v are updated in place as torch does)
-        sig_all = ops.spectral_norm_batched([m.weight_orig for m in l2 + l3], [m.weight_u for m in l2 + l3],
-                                            [m.weight_v for m in l2 + l3], training)
+        sn = ops.spectral_norm_batched([m.weight_orig for m in l2 + l3], [m.weight_u for m in l2 + l3],
+                                       [m.weight_v for m in l2 + l3], training, snapshot=need_p)
+        sig_all, usn, vsn = sn if need_p else (sn, None, None)
         sig_of = {id(m): sg for m, sg in zip(l2 + l3, sig_all)}
+        uv_of = {id(m): (usn[i], vsn[i]) for i, m in enumerate(l2 + l3)} if need_p else {}
 
         def branch(layers, specs, inp):
             recs, cur = [], inp
@@ -446,7 +448,7 @@ class _DiscriminatorFn(torch.autograd.Function):
                 act = ACT_LEAKY if n < 4 else ACT_NONE
                 y = ops.conv_fwd(spec, cur, wp_f, bias=m.bias, act=act)
                 recs.append(dict(x=cur, y=y, wp_d=wp_d, sigma=sigma, act=act,
-                                 u=m.weight_u.clone() if need_p else None, v=m.weight_v.clone() if need_p else None))
+                                 u=uv_of[id(m)][0] if need_p else None, v=uv_of[id(m)][1] if need_p else None))
                 cur = y
             return cur, recs
 

@@ -390,9 +390,10 @@ def spectral_norm(w, u, v, training: bool):
     return sigma
 
 
-def spectral_norm_batched(ws, us, vs, training: bool):
+def spectral_norm_batched(ws, us, vs, training: bool, snapshot: bool = False):
     """spectral_norm() for a list of layers in 4 launches (these kernels are launch-latency bound).  Returns the list of
-    sigma tensors (views of one buffer)."""
+    sigma tensors (views of one buffer); with snapshot=True also (u copies, v copies) of the updated vectors (the backward
+    pass needs the u, v of THIS forward; the next forward overwrites them in place)."""
     import ctypes
     lib = _hip.load()
     n = len(ws)
@@ -415,9 +416,26 @@ def spectral_norm_batched(ws, us, vs, training: bool):
     wp, up, vp = arr_p(*[w.data_ptr() for w in ws]), arr_p(*[u.data_ptr() for u in us]), arr_p(*[v.data_ptr() for v in vs])
     sp = arr_p(*[sig.data_ptr() + 4 * i for i in range(n)])
     cp = arr_p(*[scratch.data_ptr() + 4 * o for o in offs[:-1]])
-    _hip.check(lib.p2i_spectral_norm_batched(wp, arr_i(*Os), arr_i(*Ks), up, vp, int(training), sp, cp, n, _stream()),
+    usn = vsn = None
+    usp = vsp = None
+    if snapshot and training:
+        uo, vo = [0], [0]
+        for O, K in zip(Os, Ks):
+            uo.append(uo[-1] + O)
+            vo.append(vo[-1] + K)
+        ubuf = torch.empty(uo[-1], device=dev, dtype=torch.float32)
+        vbuf = torch.empty(vo[-1], device=dev, dtype=torch.float32)
+        usn = [ubuf[uo[i]:uo[i + 1]] for i in range(n)]
+        vsn = [vbuf[vo[i]:vo[i + 1]] for i in range(n)]
+        usp, vsp = arr_p(*[t.data_ptr() for t in usn]), arr_p(*[t.data_ptr() for t in vsn])
+    _hip.check(lib.p2i_spectral_norm_batched(wp, arr_i(*Os), arr_i(*Ks), up, vp, int(training), sp, cp, usp, vsp, n, _stream()),
                "p2i_spectral_norm_batched")
-    return [sig[i:i + 1] for i in range(n)]
+    sigs = [sig[i:i + 1] for i in range(n)]
+    if snapshot:
+        if not training:
+            usn, vsn = [u.clone() for u in us], [v.clone() for v in vs]
+        return sigs, usn, vsn
+    return sigs
 
 
 # --------------------------------------------------------------------------- generator glue
