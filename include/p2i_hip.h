@@ -126,6 +126,14 @@ int p2i_weight_unpack_grad(const float* dwp_f, int O, int I, int ntaps, const fl
                            const float* sigma_ptr, const float* u, const float* v, float* scratch,
                            float* dw, void* stream);
 
+/* p2i_weight_pack / p2i_weight_unpack_grad for n <= 16 layers of different shapes in one launch each (arrays of n HOST
+ * entries).  The caller zeroes padded pack outputs (pad32(O) != O or pad32(I) != I); `dots`: n floats of device scratch. */
+int p2i_weight_pack_batched(const float* const* w, const int* O, const int* I, const int* ntaps, const float* const* inv_div,
+                            float* const* wp_f, float* const* wp_d, int n, void* stream);
+int p2i_weight_unpack_grad_batched(const float* const* dwp_f, const int* O, const int* I, const int* ntaps,
+                                   const float* const* w_orig, const float* const* sigma, const float* const* u,
+                                   const float* const* v, float* dots, float* const* dw, int n, void* stream);
+
 /* ------------------------------------------------------------------ spectral norm
  * One power iteration of torch.nn.utils.spectral_norm (call sites layer.py:402-407,
  * p2igan.py:141): v <- normalize(W^T u), u <- normalize(W v), sigma = u^T W v, eps 1e-12.

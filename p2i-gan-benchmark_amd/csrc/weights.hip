@@ -508,3 +508,98 @@ extern "C" int p2i_doconv_fold_bwd_batched(const float* const* dwp_f, const floa
   hipLaunchKernelGGL(fold_bwd_d_batched_kernel, dim3(I, 1, n), dim3(256), 0, s, fb, O, I);
   return launch_status();
 }
+
+// ---- pack / unpack of up to 16 layers of DIFFERENT shapes in one launch each (blockIdx.z = layer): the discriminator's ten
+//      spectral-norm layers are packed once per forward and unpacked once per backward
+namespace p2i {
+constexpr int PACK_MAX_LAYERS = 16;
+struct PackBatch {
+  const float* w[PACK_MAX_LAYERS];
+  const float* div[PACK_MAX_LAYERS];
+  float* f[PACK_MAX_LAYERS];
+  float* d[PACK_MAX_LAYERS];
+  const float* g[PACK_MAX_LAYERS];     // unpack: packed gradient
+  const float* u[PACK_MAX_LAYERS];
+  const float* v[PACK_MAX_LAYERS];
+  float* dot[PACK_MAX_LAYERS];
+  int O[PACK_MAX_LAYERS], I[PACK_MAX_LAYERS], NT[PACK_MAX_LAYERS];
+};
+__global__ void pack_batched_kernel(const PackBatch b) {
+  const int L = blockIdx.z, O = b.O[L], I = b.I[L], NT = b.NT[L];
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < O * I * NT; idx += gridDim.x * blockDim.x) {
+    const int tap = idx % NT, i = (idx / NT) % I, o = idx / (NT * I);
+    float v = b.w[L][idx];
+    if (b.div[L]) v = v / *b.div[L];
+    if (b.f[L]) b.f[L][((size_t)tap * I + i) * pad32(O) + o] = v;
+    if (b.d[L]) b.d[L][((size_t)tap * O + o) * pad32(I) + i] = v;
+  }
+}
+__global__ void unpack_dot_batched_kernel(const PackBatch b) {
+  __shared__ float red[16];
+  const int L = blockIdx.z, O = b.O[L], I = b.I[L], NT = b.NT[L];
+  if (!b.div[L]) return;                              // plain unpack: no sigma term
+  float acc = 0.f;
+  const int n = O * I * NT;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    const int tap = idx % NT, i = (idx / NT) % I, o = idx / (NT * I);
+    acc += b.g[L][((size_t)tap * I + i) * pad32(O) + o] * b.w[L][idx];
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0 && acc != 0.f) atomicAdd(b.dot[L], acc);
+}
+__global__ void unpack_batched_kernel(const PackBatch b) {
+  const int L = blockIdx.z, O = b.O[L], I = b.I[L], NT = b.NT[L];
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < O * I * NT; idx += gridDim.x * blockDim.x) {
+    const int tap = idx % NT, i = (idx / NT) % I, o = idx / (NT * I);
+    float g = b.g[L][((size_t)tap * I + i) * pad32(O) + o];
+    if (b.div[L]) {
+      const float sg = *b.div[L];
+      g = g / sg - (*b.dot[L] / (sg * sg)) * b.u[L][o] * b.v[L][i * NT + tap];
+    }
+    b.f[L][idx] = g;
+  }
+}
+}  // namespace p2i
+
+extern "C" int p2i_weight_pack_batched(const float* const* w, const int* O, const int* I, const int* ntaps, const float* const* inv_div,
+                                       float* const* wp_f, float* const* wp_d, int n, void* stream) {
+  P2I_REQUIRE(w && O && I && ntaps && (wp_f || wp_d) && n >= 1 && n <= PACK_MAX_LAYERS, "1..%d layers", PACK_MAX_LAYERS);
+  PackBatch b{};
+  int maxn = 0;
+  for (int i = 0; i < n; ++i) {
+    P2I_REQUIRE(w[i] && O[i] > 0 && I[i] > 0 && ntaps[i] > 0, "bad layer %d", i);
+    b.w[i] = w[i]; b.div[i] = inv_div ? inv_div[i] : nullptr; b.f[i] = wp_f ? wp_f[i] : nullptr; b.d[i] = wp_d ? wp_d[i] : nullptr;
+    b.O[i] = O[i]; b.I[i] = I[i]; b.NT[i] = ntaps[i];
+    if (O[i] * I[i] * ntaps[i] > maxn) maxn = O[i] * I[i] * ntaps[i];
+  }
+  const int blocks = ceil_div(maxn, 256);
+  hipLaunchKernelGGL(pack_batched_kernel, dim3(blocks > 512 ? 512 : blocks, 1, n), dim3(256), 0, (hipStream_t)stream, b);
+  return launch_status();
+}
+
+extern "C" int p2i_weight_unpack_grad_batched(const float* const* dwp_f, const int* O, const int* I, const int* ntaps,
+                                              const float* const* w_orig, const float* const* sigma, const float* const* u,
+                                              const float* const* v, float* dots, float* const* dw, int n, void* stream) {
+  P2I_REQUIRE(dwp_f && O && I && ntaps && dw && dots && n >= 1 && n <= PACK_MAX_LAYERS, "1..%d layers", PACK_MAX_LAYERS);
+  PackBatch b{};
+  int maxn = 0;
+  bool any_sigma = false;
+  for (int i = 0; i < n; ++i) {
+    P2I_REQUIRE(dwp_f[i] && dw[i] && O[i] > 0 && I[i] > 0 && ntaps[i] > 0, "bad layer %d", i);
+    const bool sg = sigma && sigma[i];
+    P2I_REQUIRE(!sg || (w_orig && w_orig[i] && u && u[i] && v && v[i]), "spectral-norm unpack needs w_orig, u, v (layer %d)", i);
+    b.g[i] = dwp_f[i]; b.f[i] = dw[i]; b.div[i] = sg ? sigma[i] : nullptr; b.w[i] = sg ? w_orig[i] : nullptr;
+    b.u[i] = sg ? u[i] : nullptr; b.v[i] = sg ? v[i] : nullptr; b.dot[i] = dots + i;
+    b.O[i] = O[i]; b.I[i] = I[i]; b.NT[i] = ntaps[i];
+    any_sigma = any_sigma || sg;
+    if (O[i] * I[i] * ntaps[i] > maxn) maxn = O[i] * I[i] * ntaps[i];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = ceil_div(maxn, 256);
+  if (any_sigma) {
+    (void)hipMemsetAsync(dots, 0, sizeof(float) * n, s);
+    hipLaunchKernelGGL(unpack_dot_batched_kernel, dim3(blocks > 128 ? 128 : blocks, 1, n), dim3(256), 0, s, b);
+  }
+  hipLaunchKernelGGL(unpack_batched_kernel, dim3(blocks > 512 ? 512 : blocks, 1, n), dim3(256), 0, s, b);
+  return launch_status();
+}

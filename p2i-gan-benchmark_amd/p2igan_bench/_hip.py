@@ -41,6 +41,8 @@ SIGNATURES = {
     "p2i_doconv_fold_fwd_batched": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "p2i_doconv_fold_bwd_batched": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "p2i_weight_pack": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "p2i_weight_pack_batched": [_P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "p2i_weight_unpack_grad_batched": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "p2i_weight_unpack_grad": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "p2i_spectral_norm": [_P, _I, _I, _P, _P, _I, _P, _P, _P],
     "p2i_spectral_norm_batched": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],

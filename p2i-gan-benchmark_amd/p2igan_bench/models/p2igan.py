@@ -437,14 +437,17 @@ class _DiscriminatorFn(torch.autograd.Function):
         sig_all, usn, vsn = sn if need_p else (sn, None, None)
         sig_of = {id(m): sg for m, sg in zip(l2 + l3, sig_all)}
         uv_of = {id(m): (usn[i], vsn[i]) for i, m in enumerate(l2 + l3)} if need_p else {}
+        # weight / sigma, packed for the conv engine: all ten layers in ONE launch
+        wflats = [m.weight_orig.reshape(m.weight_orig.shape[0], m.weight_orig.shape[1], -1) for m in l2 + l3]
+        packed = ops.weight_pack_batched(wflats, sig_all, need_d=(need_x or need_p))
+        pack_of = {id(m): pk for m, pk in zip(l2 + l3, packed)}
 
         def branch(layers, specs, inp):
             recs, cur = [], inp
             for n, (m, spec) in enumerate(zip(layers, specs)):
                 wo = m.weight_orig
                 sigma = sig_of[id(m)]
-                wflat = wo.reshape(wo.shape[0], wo.shape[1], -1)
-                wp_f, wp_d = ops.weight_pack(wflat, sigma, need_d=(need_x or need_p))
+                wp_f, wp_d = pack_of[id(m)]
                 act = ACT_LEAKY if n < 4 else ACT_NONE
                 y = ops.conv_fwd(spec, cur, wp_f, bias=m.bias, act=act)
                 recs.append(dict(x=cur, y=y, wp_d=wp_d, sigma=sigma, act=act,
@@ -471,6 +474,7 @@ class _DiscriminatorFn(torch.autograd.Function):
         o2, o3 = r2[-1]["y"], r3[-1]["y"]
         d2, d3, da = ops.dtail_bwd(o2, tuple(o3.shape), net.alpha2d.reshape(1), dfused.contiguous().float(), need_alpha=need_alpha)
         gw, gb = {}, {}
+        pend = []                 # (layer index, packed weight gradient, flat weight, record, shape): unpacked together at the end
         arena = None
         if any(needs[:2 * nl]):
             tot = sum(sp.ntaps * sp.cin * ops.pad32(sp.cout) + sp.cout + 8 for sp in net.specs2d + net.specs3d)
@@ -484,8 +488,7 @@ class _DiscriminatorFn(torch.autograd.Function):
                 if needs[2 * (base + n)] or needs[2 * (base + n) + 1]:
                     dwp, db = ops.conv_wgrad(spec, rc["x"], dy, want_bias=True, arena=arena)
                     wo = m.weight_orig
-                    wflat = wo.reshape(wo.shape[0], wo.shape[1], -1)
-                    gw[base + n] = ops.weight_unpack_grad(dwp, wflat, wflat, rc["sigma"], rc["u"], rc["v"]).reshape(wo.shape)
+                    pend.append((base + n, dwp, wo.reshape(wo.shape[0], wo.shape[1], -1), rc, wo.shape))
                     gb[base + n] = db
                 if n > 0 or need_x:
                     dy = ops.conv_dgrad(spec, dy, rc["wp_d"], tuple(rc["x"].shape), add=first_add if n == 0 else None,
@@ -496,6 +499,11 @@ class _DiscriminatorFn(torch.autograd.Function):
 
         dx3 = branch_bwd(l3, net.specs3d, r3, d3, len(l2))
         dx = branch_bwd(l2, net.specs2d, r2, d2, 0, first_add=dx3.view(b, t * c, h, w) if dx3 is not None else None)
+        if pend:                  # d(weight_orig) through weight / sigma for every layer, in two launches
+            dws = ops.weight_unpack_grad_batched([p_[1] for p_ in pend], [p_[2] for p_ in pend], [p_[2] for p_ in pend],
+                                                 [p_[3]["sigma"] for p_ in pend], [p_[3]["u"] for p_ in pend], [p_[3]["v"] for p_ in pend])
+            for p_, dw_ in zip(pend, dws):
+                gw[p_[0]] = dw_.reshape(p_[4])
         out = []
         for i in range(nl):
             out.append(gw.get(i) if needs[2 * i] else None)

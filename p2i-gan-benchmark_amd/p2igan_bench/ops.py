@@ -361,6 +361,56 @@ def weight_pack(w, sigma=None, need_f=True, need_d=True):
     return wp_f, wp_d
 
 
+def weight_pack_batched(ws, sigmas=None, need_d=True):
+    """weight_pack for a list of (O, I, ntaps) weights (different shapes) in ONE launch; one zero-filled buffer holds every
+    packed output (the padded columns must read 0).  Returns [(wp_f, wp_d), ...]."""
+    import ctypes
+    lib = _hip.load()
+    n = len(ws)
+    Os, Is, NTs = [w.shape[0] for w in ws], [w.shape[1] for w in ws], [w.shape[2] for w in ws]
+    for w in ws:
+        if w.dim() != 3:
+            raise RuntimeError("weight_pack_batched: weights must be (O, I, ntaps)")
+        _chk(w)
+    sizes_f = [nt * i * pad32(o) for o, i, nt in zip(Os, Is, NTs)]
+    sizes_d = [nt * o * pad32(i) for o, i, nt in zip(Os, Is, NTs)] if need_d else [0] * n
+    buf = torch.zeros(sum(sizes_f) + sum(sizes_d), device=ws[0].device, dtype=torch.float32)
+    outs, off = [], 0
+    for k in range(n):
+        f = buf[off:off + sizes_f[k]].view(NTs[k], Is[k], pad32(Os[k]))
+        off += sizes_f[k]
+        d = None
+        if need_d:
+            d = buf[off:off + sizes_d[k]].view(NTs[k], Os[k], pad32(Is[k]))
+            off += sizes_d[k]
+        outs.append((f, d))
+    arr_i = ctypes.c_int * n
+    _hip.check(lib.p2i_weight_pack_batched(_ptr_array(ws), arr_i(*Os), arr_i(*Is), arr_i(*NTs),
+                                           _ptr_array(sigmas) if sigmas is not None else None, _ptr_array([o[0] for o in outs]),
+                                           _ptr_array([o[1] for o in outs]) if need_d else None, n, _stream()), "p2i_weight_pack_batched")
+    return outs
+
+
+def weight_unpack_grad_batched(dwps, likes, w_origs=None, sigmas=None, us=None, vs=None):
+    """weight_unpack_grad for a list of layers (different shapes) in two launches.  Returns [dw, ...] shaped like `likes`."""
+    import ctypes
+    lib = _hip.load()
+    n = len(dwps)
+    Os, Is, NTs = [l.shape[0] for l in likes], [l.shape[1] for l in likes], [l.shape[2] for l in likes]
+    for g, o, i, nt in zip(dwps, Os, Is, NTs):
+        if tuple(g.shape) != (nt, i, pad32(o)):
+            raise RuntimeError("weight_unpack_grad_batched: dwp shape mismatch")
+        _chk(g)
+    dws = [torch.empty_like(l) for l in likes]
+    dots = torch.empty(n, device=dwps[0].device, dtype=torch.float32)
+    arr_i = ctypes.c_int * n
+    none = [None] * n
+    _hip.check(lib.p2i_weight_unpack_grad_batched(_ptr_array(dwps), arr_i(*Os), arr_i(*Is), arr_i(*NTs), _ptr_array(w_origs or none),
+                                                  _ptr_array(sigmas or none), _ptr_array(us or none), _ptr_array(vs or none),
+                                                  _ptr(dots), _ptr_array(dws), n, _stream()), "p2i_weight_unpack_grad_batched")
+    return dws
+
+
 def weight_unpack_grad(dwp_f, like, w_orig=None, sigma=None, u=None, v=None):
     lib = _hip.load()
     O, I = like.shape[0], like.shape[1]

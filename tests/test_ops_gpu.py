@@ -439,3 +439,21 @@ def test_doconv_fold_batched_matches_per_layer(ops):
     dWs, dDs = ops.doconv_fold_bwd_batched(dwps, layers, O, I)
     for (rW, rD), dW, dD in zip(ref, dWs, dDs):
         assert torch.equal(rW, dW) and rel_err(dD.cpu().numpy(), rD.cpu().numpy()) < 1e-6
+
+
+def test_weight_pack_unpack_batched_match_per_layer(ops):
+    """p2i_weight_pack_batched / p2i_weight_unpack_grad_batched (ten differently shaped layers per launch) == per-layer calls."""
+    shapes = [(64, 16, 9), (128, 64, 9), (1, 256, 9), (32, 1, 27), (1, 128, 1)]
+    ws = [_rand(*sh, seed=70 + i, scale=0.1).cuda() for i, sh in enumerate(shapes)]
+    sig = [torch.tensor([1.5 + 0.1 * i]).cuda() for i in range(len(ws))]
+    one = [ops.weight_pack(w, s_) for w, s_ in zip(ws, sig)]
+    bat = ops.weight_pack_batched(ws, sig, need_d=True)
+    for (f1, d1), (f2, d2) in zip(one, bat):
+        assert torch.equal(f1, f2) and torch.equal(d1, d2)
+    dwps = [_rand(*f.shape, seed=80 + i).cuda() for i, (f, _) in enumerate(one)]
+    us = [F.normalize(_rand(w.shape[0], seed=90 + i), dim=0).cuda() for i, w in enumerate(ws)]
+    vs = [F.normalize(_rand(w.shape[1] * w.shape[2], seed=95 + i), dim=0).cuda() for i, w in enumerate(ws)]
+    ref = [ops.weight_unpack_grad(g, w, w, s_, u, v) for g, w, s_, u, v in zip(dwps, ws, sig, us, vs)]
+    got = ops.weight_unpack_grad_batched(dwps, ws, ws, sig, us, vs)
+    for r, g_ in zip(ref, got):
+        assert rel_err(g_.cpu().numpy(), r.cpu().numpy()) < 1e-5
