@@ -1,6 +1,6 @@
 import csv, collections, glob, sys
 d=sys.argv[1]; nsteps=int(sys.argv[2]) if len(sys.argv)>2 else 7
-f=glob.glob(d+"/*/*kernel_trace.csv")[0]
+f=(glob.glob(d+"/*kernel_trace.csv")+glob.glob(d+"/*/*kernel_trace.csv"))[0]
 rows=list(csv.DictReader(open(f)))
 agg=collections.defaultdict(list)
 for r in rows:
