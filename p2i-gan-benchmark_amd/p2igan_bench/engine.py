@@ -71,6 +71,9 @@ class TrainEngine:
         betas = (opt_cfg.get("beta1", 0.0), opt_cfg.get("beta2", 0.99))
         self.gp = FlatParams(self.G)
         self.opt_g = FusedAdam(self.gp, opt_cfg["lr"], betas)
+        # this engine zeroes the flat gradient buffer before every backward and runs G once per backward: the generator's
+        # backward may write weight gradients straight into the .grad views (models/p2igan.py, eblock_bwd)
+        self.G._grads_inplace = True
         self.dp = self.opt_d = None
         if self.use_gan:
             self.dp = FlatParams(self.D)

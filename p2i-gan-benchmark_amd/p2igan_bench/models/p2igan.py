@@ -284,9 +284,16 @@ class _GeneratorFn(torch.autograd.Function):
                 dwp1, _ = ops.conv_wgrad(spec, hin, dy1, arena=arena)
                 pend.append((dwp1, c1))
                 dh = ops.conv_dgrad(spec, dy1, w1d, tuple(hin.shape), add=dh)                     # + skip path
-            dWs, dDs = ops.doconv_fold_bwd_batched([g_ for g_, _ in pend], [cv.tensors() for _, cv in pend], ch, ch)
-            for (_, cv), dW_, dD_ in zip(pend, dWs, dDs):
-                grads[id(cv.W)], grads[id(cv.D)] = dW_, dD_
+            # TrainEngine mode: the results go straight into the flat gradient buffer (each .grad is a view of it, zeroed
+            # before every backward, each parameter used once) and None is returned for these inputs -> no AccumulateGrad
+            # add kernel per tensor.  Anyone else gets ordinary returned gradients.
+            inplace = getattr(net, "_grads_inplace", False) and all(
+                cv.W.grad is not None and cv.D.grad is not None and cv.W.grad.is_contiguous() and cv.D.grad.is_contiguous() for _, cv in pend)
+            outs = ([cv.W.grad for _, cv in pend], [cv.D.grad for _, cv in pend]) if inplace else None
+            dWs, dDs = ops.doconv_fold_bwd_batched([g_ for g_, _ in pend], [cv.tensors() for _, cv in pend], ch, ch, outs=outs)
+            if not inplace:
+                for (_, cv), dW_, dD_ in zip(pend, dWs, dDs):
+                    grads[id(cv.W)], grads[id(cv.D)] = dW_, dD_
             return dh
 
         def uppos_bwd(i, dr):

@@ -330,8 +330,9 @@ def doconv_fold_batched(layers, out_ch, in_ch, need_d=True):
     return [(wf[i], wd[i] if need_d else None) for i in range(n)]
 
 
-def doconv_fold_bwd_batched(dwps, layers, out_ch, in_ch):
-    """doconv_fold_bwd for same-shape layers in TWO launches.  Returns ([dW...], [dD...])."""
+def doconv_fold_bwd_batched(dwps, layers, out_ch, in_ch, outs=None):
+    """doconv_fold_bwd for same-shape layers in TWO launches.  Returns ([dW...], [dD...]).  outs = ([dW targets], [dD targets])
+    writes the results straight into caller-owned tensors (the flat gradient buffer's views)."""
     lib = _hip.load()
     n = len(layers)
     if len(dwps) != n:
@@ -341,12 +342,20 @@ def doconv_fold_bwd_batched(dwps, layers, out_ch, in_ch):
             raise RuntimeError("doconv_fold_bwd_batched: dwp shape mismatch")
         _chk(g)
     dev = dwps[0].device
-    dW = torch.empty((n, out_ch, in_ch, 9), device=dev, dtype=torch.float32)
-    dD = torch.empty((n, in_ch, 9, 9), device=dev, dtype=torch.float32)
+    if outs is not None:
+        dWs, dDs = outs
+        for t, shp in [(t, (out_ch, in_ch, 9)) for t in dWs] + [(t, (in_ch, 9, 9)) for t in dDs]:
+            if tuple(t.shape) != shp:
+                raise RuntimeError("doconv_fold_bwd_batched: output target shape mismatch")
+            _chk(t)
+    else:
+        dW = torch.empty((n, out_ch, in_ch, 9), device=dev, dtype=torch.float32)
+        dD = torch.empty((n, in_ch, 9, 9), device=dev, dtype=torch.float32)
+        dWs, dDs = [dW[i] for i in range(n)], [dD[i] for i in range(n)]
     _hip.check(lib.p2i_doconv_fold_bwd_batched(_ptr_array(dwps), _ptr_array([l[0] for l in layers]), _ptr_array([l[1] for l in layers]),
-                                               _ptr_array([l[2] for l in layers]), n, out_ch, in_ch, _ptr_array([dW[i] for i in range(n)]),
-                                               _ptr_array([dD[i] for i in range(n)]), _stream()), "p2i_doconv_fold_bwd_batched")
-    return [dW[i] for i in range(n)], [dD[i] for i in range(n)]
+                                               _ptr_array([l[2] for l in layers]), n, out_ch, in_ch, _ptr_array(dWs),
+                                               _ptr_array(dDs), _stream()), "p2i_doconv_fold_bwd_batched")
+    return dWs, dDs
 
 
 def weight_pack(w, sigma=None, need_f=True, need_d=True):
