@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: P2I-GAN train frames/s on synthetic (B,16,1,128,128) events (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N>1 either arrives through `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when WORLD_SIZE is unset, bench.py starts the N ranks
+itself: the parent spawns N fresh child processes BEFORE touching the GPU (no HIP call, no re-exec), waits for them and
+exits non-zero if any of them fails.  A WORLD_SIZE that disagrees with --gpus is an error, never a silent 1-rank run.
 
 One "step" = one full G+D training iteration (train.py:240-326: G fwd, rec loss, D fwd x2 + D bwd +
 Adam-D, D fwd + adv loss, G bwd through D, Adam-G) on one batch already resident in HBM.
@@ -11,6 +16,8 @@ Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` and `cpu_
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -54,6 +61,127 @@ def cpu_baseline(batch, steps, threads):
             "sample": f"{steps} full train steps at B={batch} (T=16,128x128, 79 gauges/frame) after 1 warm-up, {dt:.2f} s/step"}
 
 
+def launch_ranks(n: int) -> int:
+    """Parent side of `--gpus N` without a launcher: N child processes, one per GPU, env contract of
+    torch.distributed.run.  The parent never initialises the GPU; rank 0's child prints the JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:                       # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def physical_cores():
+    """(cores this process may use, of which distinct physical cores): affinity mask, cgroup quota, SMT siblings."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    avail = len(cpus)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            avail = max(1, min(avail, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cores = set()
+    for c in cpus:
+        try:
+            cores.add(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip())
+        except OSError:
+            cores.add(str(c))
+    return avail, max(1, min(avail, len(cores)))
+
+
+def stub_main(args, world, rank):
+    """Launcher self-test (tests/test_bench_launch_cpu.py; P2I_BENCH_STUB=1 only): same rank / barrier / max-over-ranks /
+    one-JSON-line plumbing over gloo on CPU with a stand-in step.  Never a measurement: the line says so."""
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    buf = torch.ones(1024) * (rank + 1)
+
+    def step():
+        time.sleep(0.002)
+        if world > 1:
+            dist.all_reduce(buf)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+    if os.environ.get("P2I_BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    if rank == 0:
+        print(json.dumps({"metric": "train frames/sec (128x128x16)", "value": world * args.batch * T * args.steps / dt, "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "data": "STUB STEP (launcher self-test, not a measurement)",
+                          "config": {"global_batch": args.batch * world, "parallelism": "dp%d" % world}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def stack_b32(dev, batch=32, iters=10):
+    """north_star target figure: one DO-Conv 3x3 C->C layer of each generator level (C, S) at B=32, forward + dgrad (with
+    the residual add) + wgrad, HIP events on the launch stream, against the fp32-matrix peak."""
+    from p2igan_bench import ops
+    levels, tot_f, tot_s = {}, 0.0, 0.0
+    for C, S in ((64, H), (128, H // 2), (256, H // 4), (512, H // 8)):
+        spec = ops.ConvSpec(C, C, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+        x = torch.randn(batch, C, S, S * W // H, device=dev)
+        dy = torch.randn_like(x)
+        wp_f, wp_d = ops.weight_pack(torch.randn(C, C, 9, device=dev) * 0.05)
+        fl = 2.0 * batch * C * C * 9 * x.shape[2] * x.shape[3]
+        row = {}
+        for kind, fn in (("fwd", lambda: ops.conv_fwd(spec, x, wp_f, act=ops.ACT_RELU)),
+                         ("dgrad", lambda: ops.conv_dgrad(spec, dy, wp_d, tuple(x.shape), add=x)),
+                         ("wgrad", lambda: ops.conv_wgrad(spec, x, dy))):
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            sec = e0.elapsed_time(e1) * 1e-3 / iters
+            row[kind] = round(fl / sec / 1e12, 1)
+            tot_f += fl
+            tot_s += sec
+        levels["C%d@%d" % (C, S)] = row
+        del x, dy
+    ach = tot_f / tot_s / 1e12
+    return {"what": "generator 3x3 DO-Conv stack, one layer per level, fwd+dgrad+wgrad, B=%d, f32 MFMA" % batch, "bound": "mfma",
+            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "gflop": round(tot_f / 1e9, 1), "ms": round(tot_s * 1e3, 3), "tflops_by_level": levels}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,19 +195,32 @@ def main():
     ap.add_argument("--graph", choices=("on", "off"), default="off",
                     help="replay the whole G+D step as one hipGraph (single GPU).  Off by default: at B=8 the step is bound by "
                          "kernel time, not by dispatch gaps (28.6 ms replayed vs 28.8 ms eager, profiles/README.md)")
+    ap.add_argument("--no-stack", action="store_true", help="skip the B=32 generator conv-stack figure (roofline_b32_stack)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:                              # no launcher above us: start the N ranks, touch nothing else
+            raise SystemExit(launch_ranks(args.gpus))
+        world = 1
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; refusing to report a mislabelled line")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("P2I_BENCH_STUB") == "1":
+        return stub_main(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from p2igan_bench import _hip, ops
     from p2igan_bench.engine import TrainEngine
@@ -158,14 +299,18 @@ def main():
         dom = max(single, key=lambda k: single[k]["seconds"])
         d = single[dom]
         ach = d["flops"] / d["seconds"] / 1e12
-        traffic = None
+        # HBM bytes per launch from the committed PMC passes (static: counters cannot be read inside this run).  Corrected as
+        # MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 (16-B-per-lane LDS-DMA streams), WRITE_SIZE as read.
+        traffic = traffic_src = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get(dom)
+            tj = json.load(open(pmc))
+            traffic = tj.get("kernels", tj).get(dom)
+            traffic_src = tj.get("source")
         note = ("HIP events bracket the p2i_conv_wgrad_ws call = this kernel + its wgrad_reduce_kernel (rocprofv3 lists them separately)"
                 if dom.startswith("wgrad_dma_kernel") and ops.WGRAD_SLICES else None)
         roofline = {"bound": "mfma", "kernel": dom, "note": note, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_us": round(d["seconds"] / d["launches"] * 1e6, 2),
                     "flops_per_launch": d["flops"] / d["launches"], "launches_per_step": d["launches"] / nprof}
         tot_s = sum(v["seconds"] for v in summ.values())
@@ -177,10 +322,15 @@ def main():
     if world > 1:
         dist.barrier()
 
+    if rank == 0 and world == 1 and not args.no_stack:
+        extra["roofline_b32_stack"] = stack_b32(dev)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = min(os.cpu_count() or 1, int(os.environ.get("P2I_CPU_THREADS", "16")))
+        avail, phys = physical_cores()                 # all physical cores this process may use
+        threads = int(os.environ.get("P2I_CPU_THREADS", phys))
         cpu = cpu_baseline(args.cpu_batch, args.cpu_steps, threads)
+        cpu["cores_available"] = avail
 
     if rank == 0:
         line = {"metric": "train frames/sec (128x128x16)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
