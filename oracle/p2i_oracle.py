@@ -17,7 +17,9 @@ import torch.nn.functional as F
 
 Params = Dict[str, torch.Tensor]
 
-BASE_CH = 64          # p2igan.py:46
+BASE_CH = 64          # p2igan.py:46 (T = 16).  T != 16 has no reference behaviour (layer.py:310 raises); the build's
+                      # generalisation base = 4*T is restated below so that the HIP path has a checker:
+                      # "parity unpinned -- self-consistency only" for T != 16.
 NUM_RES = 4           # p2igan.py:24
 IDW_K, IDW_RHO, IDW_TAU, IDW_CHUNK = 4, 2.0, 0.05, 16384   # p2igan.py:44
 # "c": pinned host-independent selection (parity checks); "torch": literal cdist/topk as the reference
@@ -198,7 +200,7 @@ def uppos(p: Params, i: int, x: torch.Tensor) -> torch.Tensor:
 
 def eblock(p: Params, lvl: int, x: torch.Tensor) -> torch.Tensor:
     """EBlock (p2igan.py:176-183) of 4 ResBlock_do (layer.py:126-135)."""
-    c = BASE_CH << lvl
+    c = x.shape[1]
     for r in range(NUM_RES):
         pre = f"Decoder.{lvl}.layers.{r}.main"
         y = F.relu(doconv(p, pre + ".0.main.0", x, c, c, 1, 3))
@@ -214,18 +216,20 @@ def generator_forward(p: Params, masked_frames: torch.Tensor, masks: torch.Tenso
     mf = masked_frames.reshape(b, c * t, h, w)
     mk = masks.reshape(b, c * t, h, w)
     x = input_block(p, mf, mk).float()
-    x_ = doconv(p, "Convsin.0.main.0", x, BASE_CH, t, 4, 3) + x.repeat_interleave(4, dim=1)
+    base = 4 * t                                              # 64 at the reference's T = 16
+    x_ = doconv(p, "Convsin.0.main.0", x, base, t, 4, 3) + x.repeat_interleave(4, dim=1)
     x_2 = pool_dup(x_, t)
     x_4 = pool_dup(x_2, t)
     x_8 = pool_dup(x_4, t)
-    res1 = uppos(p, 2, eblock(p, 3, x_8))
+    dec3 = eblock(p, 3, x_8)
+    res1 = uppos(p, 2, dec3)
     x_4 = x_4 + res1
     res2 = uppos(p, 1, eblock(p, 2, x_4))
     res3 = uppos(p, 0, eblock(p, 1, res2))
     z = eblock(p, 0, res3)
-    z = doconv(p, "ConvsOut.0.main.0", z, t, BASE_CH, 4, 1)
+    z = doconv(p, "ConvsOut.0.main.0", z, t, base, 4, 1)
     if taps is not None:
-        taps.update(idw=x, x_=x_, x_8=x_8, res1=res1, res3=res3)
+        taps.update(idw=x, x_=x_, x_8=x_8, dec3=dec3, res1=res1, res3=res3)
     return torch.tanh(z).view(b, t, c, h, w)
 
 
@@ -363,10 +367,10 @@ class TrainState:
         self.b1 = cfg_opt.get("beta1", 0.0)
         self.b2 = cfg_opt.get("beta2", 0.99)
 
-    def step(self, frames, masked, masks, keep_grads: bool = False):
+    def step(self, frames, masked, masks, keep_grads: bool = False, taps: Optional[dict] = None):
         for k in self.gkeys:
             self.gp[k].requires_grad_(True)
-        preds = generator_forward(self.gp, masked, masks)
+        preds = generator_forward(self.gp, masked, masks, taps)
         loss_g, pool, reg = reconstruction_loss(preds, frames, self.k1)
         out = {"rec": float(loss_g.detach()), "pool": float(pool.detach()), "reg": float(reg.detach())}
         dgrads = None

@@ -390,16 +390,24 @@ using namespace p2i;
 extern "C" int p2i_attn_fwd(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, float* out,
                             int B, int T, int HW, void* stream) {
   P2I_REQUIRE(x && w0 && b0 && w1 && b1 && out, "null pointer");
-  P2I_REQUIRE(T == 16, "AttentionBlock is hard-wired to T=16 (layer.py:310)");
-  hipLaunchKernelGGL(attn_fwd_kernel<16>, dim3(ceil_div(HW, 256), B), dim3(256), 0, (hipStream_t)stream, x, w0, b0, w1, b1, out, B, HW);
+  // T = 16 is the reference (layer.py:310); 8 and 32 are this build's generalisation (parity unpinned)
+  P2I_REQUIRE(T == 8 || T == 16 || T == 32, "AttentionBlock kernels exist for T in {8, 16, 32}");
+  const dim3 grid(ceil_div(HW, 256), B);
+  hipStream_t s = (hipStream_t)stream;
+  if (T == 16) hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, out, B, HW);
+  else if (T == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, out, B, HW);
+  else hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, out, B, HW);
   return launch_status();
 }
 extern "C" int p2i_attn_bwd(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
                             const float* dout, float* dw0, float* db0, float* dw1, float* db1, int B, int T, int HW, void* stream) {
   P2I_REQUIRE(x && w0 && b0 && w1 && b1 && dout && dw0 && db0 && dw1 && db1, "null pointer");
-  P2I_REQUIRE(T == 16, "AttentionBlock is hard-wired to T=16 (layer.py:310)");
-  hipLaunchKernelGGL(attn_bwd_kernel<16>, dim3(ceil_div(HW, 256), B), dim3(256), 0, (hipStream_t)stream, x, w0, b0, w1, b1, dout,
-                     dw0, db0, dw1, db1, B, HW);
+  P2I_REQUIRE(T == 8 || T == 16 || T == 32, "AttentionBlock kernels exist for T in {8, 16, 32}");
+  const dim3 grid(ceil_div(HW, 256), B);
+  hipStream_t s = (hipStream_t)stream;
+  if (T == 16) hipLaunchKernelGGL(attn_bwd_kernel<16>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW);
+  else if (T == 32) hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW);
+  else hipLaunchKernelGGL(attn_bwd_kernel<8>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW);
   return launch_status();
 }
 extern "C" int p2i_pooldup_fwd(const float* x, float* y, int B, int C, int H, int W, void* stream) {

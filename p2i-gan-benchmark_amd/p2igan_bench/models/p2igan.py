@@ -19,7 +19,8 @@ from torch.nn import init
 from .. import ops
 from ..ops import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH, ConvSpec
 
-BASE_CH = 64
+BASE_CH = 64                      # p2igan.py:46 (T = 16); the build's generalisation is base = 4 * T, see P2IGenerator
+SUPPORTED_T = (8, 16, 32)         # AttentionBlock kernel instantiations (csrc/glue.hip)
 
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -105,21 +106,27 @@ class P2IGenerator(nn.Module):
         self.H = data_cfg["h"]
         self.W = data_cfg["w"]
         length = data_cfg.get("sample_length", length)
-        if length != 16:
-            raise RuntimeError("P2IGenerator is hard-wired to T=16 in the reference (AttentionBlock(16), layer.py:310)")
+        # The reference is hard-wired to T = 16 (AttentionBlock(16) layer.py:310, base_channel 64 = 4*16 with
+        # repeat_interleave(4) p2igan.py:46,66,79) and raises for anything else.  BASELINE configs[4] asks for T = 32, so
+        # this build generalises the way SURVEY.md H5 prescribes: AttentionBlock(T), Convsin T -> 4T (groups 4),
+        # base_channel = 4T, ConvsOut 4T -> T, discriminator in_channels = T.  T = 16 is unchanged (same keys, shapes and
+        # arithmetic); T != 16 has NO reference behaviour: "parity unpinned -- self-consistency with the oracle only".
+        if length not in SUPPORTED_T:
+            raise RuntimeError(f"P2IGenerator: sample_length {length} not in {SUPPORTED_T} (the reference itself only runs T=16, layer.py:310)")
         self.length = length
+        self.base = base = 4 * length
         self.num_res = num_res
         self.inference = inference
         # construction order == reference (p2igan.py:44-67) so that torch's RNG is consumed identically
         self.input = _InputParams(depth=2, t=length)
-        self.Decoder = nn.ModuleList([_EBlockParams(BASE_CH << l, num_res, folded=inference) for l in range(4)])
-        self.ConvsOut = nn.ModuleList([_basic_conv(BASE_CH, length, 1, groups=4, folded=inference)])
+        self.Decoder = nn.ModuleList([_EBlockParams(base << l, num_res, folded=inference) for l in range(4)])
+        self.ConvsOut = nn.ModuleList([_basic_conv(base, length, 1, groups=4, folded=inference)])
         self.UP = nn.ModuleList([
-            _UPPosParams(BASE_CH * 2, BASE_CH, self.H, self.W),
-            _UPPosParams(BASE_CH * 4, BASE_CH * 2, self.H // 2, self.W // 2),
-            _UPPosParams(BASE_CH * 8, BASE_CH * 4, self.H // 4, self.W // 4),
+            _UPPosParams(base * 2, base, self.H, self.W),
+            _UPPosParams(base * 4, base * 2, self.H // 2, self.W // 2),
+            _UPPosParams(base * 8, base * 4, self.H // 4, self.W // 4),
         ])
-        self.Convsin = nn.ModuleList([_basic_conv(length, BASE_CH, 3, groups=4, folded=inference)])
+        self.Convsin = nn.ModuleList([_basic_conv(length, base, 3, groups=4, folded=inference)])
         if init_weights:
             self.init_weights()
         self._pnames = [n for n, _ in self.named_parameters()]
@@ -127,6 +134,7 @@ class P2IGenerator(nn.Module):
         # (sliding-window inference calls the generator once per window batch): see _cached()
         self._wp_cache = {}
         self._weights_epoch = 0
+        self.debug_taps = None      # set to a dict to receive intermediate tensors of the next forward (tests localise regressions)
 
     def invalidate_weight_cache(self):
         """Must be called by anything that rewrites parameters behind autograd's back (FusedAdam's raw-pointer
@@ -157,12 +165,12 @@ class P2IGenerator(nn.Module):
         if not hasattr(self, "_arena_n"):
             n = 0
             for lvl in range(4):
-                ch = BASE_CH << lvl
+                ch = self.base << lvl
                 n += 2 * self.num_res * 9 * ch * ops.pad32(ch)
             for up in self.UP:
                 co, ci = up.proj.weight.shape[0], up.proj.weight.shape[1]
                 n += ci * ops.pad32(co) + co + 8
-            n += 9 * self.length * ops.pad32(BASE_CH) + BASE_CH * ops.pad32(self.length) + 64
+            n += 9 * self.length * ops.pad32(self.base) + self.base * ops.pad32(self.length) + 64
             self._arena_n = n
         return self._arena_n
 
@@ -182,6 +190,7 @@ class _GeneratorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net: P2IGenerator, masked_frames, masks, *params):
         b, t, c, h, w = masked_frames.shape
+        BASE_CH = net.base
         if c != 1 or t != net.length:
             raise RuntimeError(f"generator expects (B,{net.length},1,H,W), got {tuple(masked_frames.shape)}")
         if h % 8 or w % 8:
@@ -249,6 +258,8 @@ class _GeneratorFn(torch.autograd.Function):
         wp_out = fold(cout, t, BASE_CH, 4, 1)
         spec_out = _spec2d(BASE_CH, t, 1)
         z = ops.conv_fwd(spec_out, h0, wp_out[0], act=ACT_TANH)
+        if net.debug_taps is not None:
+            net.debug_taps.update(idw=idw, x_=x_, x_8=x_8, dec3=h3, res1=res1, res3=res3)
         if need_grad:
             ctx.net = net
             ctx.S = dict(x0=x0, idw=idw, sel=sel, wp_in_d=wp_in[1], x_=x_, x_2=x_2, x_4=x_4,
@@ -260,6 +271,7 @@ class _GeneratorFn(torch.autograd.Function):
     def backward(ctx, dout):
         net, S = ctx.net, ctx.S
         b, t, h, w = S["shape"]
+        BASE_CH = net.base
         grads = {}
         arena = ops.ZeroArena(net._arena_numel(), dout.device)
         dz = dout.reshape(b, t, h, w).contiguous().float()
@@ -390,6 +402,7 @@ class P2IDiscriminator(nn.Module):
         self.d3d = nn.Sequential(*mods)
         self.alpha2d = nn.Parameter(torch.tensor(0.0))
         self.alpha3d = nn.Parameter(torch.tensor(0.0))      # declared but unused by forward (p2igan.py:145,170)
+        self.debug_taps = None
         if init_weights:
             self.init_weights()
         self.specs2d, cin = [], in_channels
@@ -465,6 +478,8 @@ class _DiscriminatorFn(torch.autograd.Function):
         o2, r2 = branch(l2, net.specs2d, xin.view(b, t * c, h, w))
         o3, r3 = branch(l3, net.specs3d, xin.view(b, c, t, h, w))      # permute(0,2,1,3,4) with c == 1 is a view
         fused = ops.dtail_fwd(o2, o3, net.alpha2d.reshape(1))
+        if net.debug_taps is not None:
+            net.debug_taps.update(out2d=o2, out3d=o3)
         if need_x or need_p:
             ctx.net, ctx.r2, ctx.r3, ctx.xshape = net, r2, r3, (b, t, c, h, w)
         return fused

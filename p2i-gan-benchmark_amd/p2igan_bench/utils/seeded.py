@@ -36,8 +36,9 @@ def _unit(seed, name, n):
     return torch.from_numpy(v.astype(np.float32))
 
 
-def generator_shapes(h: int, w: int, t: int = 16, base: int = 64) -> Dict[str, Tuple[int, ...]]:
-    """state_dict keys/shapes of P2IGenerator (p2igan.py:44-67) in the reference's order."""
+def generator_shapes(h: int, w: int, t: int = 16, base: int = 0) -> Dict[str, Tuple[int, ...]]:
+    """state_dict keys/shapes of P2IGenerator (p2igan.py:44-67) in the reference's order (base = 4t: 64 at T=16)."""
+    base = base or 4 * t
     s: Dict[str, Tuple[int, ...]] = {}
     for i in range(2):
         s[f"input.layers.{i}.conv.weight"] = (t, t, 1)

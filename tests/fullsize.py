@@ -1,0 +1,57 @@
+"""Shared checker for the full-size train-step goldens (e2e_128.npz / e2e_256.npz, tests/golden/make_golden.py::_full_step):
+used by the oracle's CPU test and by the HIP path's GPU tests, so both are held to the reference by the same rules."""
+import numpy as np
+import torch
+
+from conftest import rel_err
+
+TOL = 1e-4          # north_star: 1e-4 relative to max-abs, fp32
+GTOL = 1e-3         # gradients after long reductions / quantities after an Adam step
+
+
+def batch_for(g, h, w):
+    from p2igan_bench.utils import seeded
+    if h == 128:
+        ms = [seeded.gauge_mask(128, 128, 79), seeded.block_mask(128, 128, 10, seed=13)]
+    else:
+        ms = [seeded.block_mask(256, 256, 20, seed=1)]
+    parts = [seeded.synthetic_batch(1, 16, h, w, m, seed=2024 + 1000 * i) for i, m in enumerate(ms[:int(g["batch"])])]
+    return tuple(torch.cat([p[j] for p in parts]) for j in range(3))
+
+
+def check(g, r, ggrads, dgrads, gstate, dstate, taps=None):
+    """g: golden npz; r: dict with preds, logits_fake, logits_real, loss_g, loss_d, adv, pool, reg (tensors or floats);
+    ggrads / dgrads: name -> gradient of the step; gstate / dstate: state after the step; taps: optional idw / dec3 / res3."""
+    s = int(g["lattice"])
+    f = lambda v: float(v)
+    n_ = lambda t: t.detach().cpu().numpy()
+    preds = n_(r["preds"])
+    assert rel_err(preds[:, :, 0, ::s, ::s], g["preds_lat"]) < TOL
+    assert abs(float(np.float64(preds.astype(np.float64).sum())) - f(g["preds_sum"])) < TOL * f(g["preds_abs_sum"])
+    assert rel_err(n_(r["logits_fake"]), g["logits_fake"]) < TOL
+    assert rel_err(n_(r["logits_real"]), g["logits_real"]) < TOL
+    for k in ("loss_g", "loss_d", "pool", "reg"):
+        assert abs(f(r[k]) - f(g[k])) <= TOL * abs(f(g[k])), (k, f(r[k]), f(g[k]))
+    # adv is evaluated after D's Adam step (beta1 = 0: a sign update; a gradient whose sign flips under summation-order
+    # noise moves a weight by 2e-4): documented looser bound
+    assert abs(f(r["adv"]) - f(g["adv"])) <= 2e-3 * abs(f(g["adv"]))
+    if taps:
+        assert rel_err(n_(taps["idw"])[:, :, ::s, ::s], g["idw_lat"]) < 1e-5
+        assert rel_err(n_(taps["dec3"])[:, ::16], g["dec3_lat"]) < TOL
+        assert rel_err(n_(taps["res3"])[:, ::5, ::s, ::s], g["res3_lat"]) < TOL
+    for k in g.files:
+        kind, _, name = k.partition("/")
+        if kind == "ggradnorm":
+            assert abs(f(ggrads[name].norm()) - f(g[k])) <= GTOL * f(g[k]) + 1e-7, k
+        elif kind == "dgradnorm":
+            assert abs(f(dgrads[name].norm()) - f(g[k])) <= GTOL * f(g[k]) + 1e-7, k
+        elif kind == "ggrad":
+            assert rel_err(n_(ggrads[name]), g[k]) < GTOL, k
+        elif kind == "dgrad":
+            assert rel_err(n_(dgrads[name]), g[k]) < GTOL, k
+        elif kind == "g1sum":
+            assert abs(f(gstate[name].double().sum()) - f(g[k])) <= 2e-3 * max(1.0, abs(f(g[k]))), k
+        elif kind == "d1sum":
+            assert abs(f(dstate[name].double().sum()) - f(g[k])) <= 2e-3 * max(1.0, abs(f(g[k]))), k
+    assert rel_err(n_(dstate["d3d.0.weight_u"]), g["d1/d3d.0.weight_u"]) < TOL
+    assert rel_err(n_(dstate["d2d.6.weight_v"]), g["d1/d2d.6.weight_v"]) < TOL

@@ -220,6 +220,93 @@ def case_g_128():
     print("g_128: preds mean", float(preds.mean()))
 
 
+def _full_step(h, w, batch, masks_hw, lattice, out_name, big_grads=True):
+    """ONE full G+D train step of the genuine reference (train.py:240-326; Adam lr 1e-4 betas (0, 0.99), hinge, k1 0.05,
+    adv 0.01) at full spatial size: everything the HIP path's backward / wgrad / spectral-norm gradient / Adam produce at
+    this size is pinned through losses, logits, the gradient norm of EVERY parameter, full gradients of a few small
+    tensors and parameter checksums after the step.  preds are stored on a `lattice`-strided grid."""
+    from torch.optim import Adam
+    G, D = build(h, w)
+    G.train(); D.train()
+    parts = [seeded.synthetic_batch(1, 16, h, w, m, seed=2024 + 1000 * i) for i, m in enumerate(masks_hw[:batch])]
+    frames, masked, masks = (torch.cat([p_[j] for p_ in parts]) for j in range(3))
+    taps = {}
+    hooks = [G.input.register_forward_hook(lambda m, i, o: taps.__setitem__("idw", o.detach().clone())),
+             G.Decoder[3].register_forward_hook(lambda m, i, o: taps.__setitem__("dec3", o.detach().clone())),
+             G.UP[0].register_forward_hook(lambda m, i, o: taps.__setitem__("res3", o.detach().clone()))]
+    opt_g = Adam(G.parameters(), lr=1e-4, betas=(0.0, 0.99))
+    opt_d = Adam(D.parameters(), lr=1e-4, betas=(0.0, 0.99))
+    rec = ReconstructionLoss(k1_alpha=0.05)
+    res = {}
+    preds = G(masked, masks)
+    loss_g, ld = rec(preds, frames, masks)
+    for p in D.parameters():
+        p.requires_grad_(True)
+    lf = D(preds.detach())
+    lr_ = D(frames)
+    loss_d = (gan_loss(lr_, True, loss_type="hinge", is_disc=True) + gan_loss(lf, False, loss_type="hinge", is_disc=True)) * 0.5
+    opt_d.zero_grad(); loss_d.backward()
+    res.update({"dgradnorm/" + n: np.float32(p.grad.norm().item()) for n, p in D.named_parameters() if p.grad is not None})
+    for n in ("d2d.0.weight_orig", "d2d.8.weight_orig", "d2d.8.bias", "d3d.0.weight_orig", "d3d.0.bias", "d3d.8.weight_orig", "alpha2d"):
+        res["dgrad/" + n] = np_(dict(D.named_parameters())[n].grad)
+    opt_d.step()
+    for p in D.parameters():
+        p.requires_grad_(False)
+    lg = D(preds)
+    adv = gan_loss(lg, True, loss_type="hinge", is_disc=False) * 0.01
+    loss_g = loss_g + adv
+    opt_g.zero_grad(); loss_g.backward(); opt_g.step()
+    # IDW rank-4/5 distance ties: which of two exactly tied gauges torch.topk keeps depends on sub-ulp behaviour of the
+    # host's MKL (sgemm accumulation order, VML sqrt: 0.6 % of its results are 1 ulp below the correctly rounded value),
+    # so the reference itself is host-dependent at such voxels (typically 0-7 of a sample's 262 144, DESIGN.md section 2).  The
+    # fixture masks are chosen (seed scan) so that the pinned selection of oracle/idw_knn.c equals what this host's
+    # torch did at EVERY voxel; the count is asserted and recorded.
+    sys.path.insert(0, ROOT)
+    from oracle import p2i_oracle as orc
+    with torch.no_grad():
+        idw_o = orc.input_block(seeded.seeded_generator_state(h, w), masked.reshape(batch, 16, h, w), masks.reshape(batch, 16, h, w))
+    tie_vox = int(((idw_o - taps["idw"]).abs() > 1e-6 * float(taps["idw"].abs().max())).sum())
+    assert tie_vox == 0, f"{tie_vox} voxels where the pinned IDW selection differs from this host's torch.topk: pick another mask seed"
+    res["idw_tie_voxels"] = np.int32(tie_vox)
+    s = lattice
+    res.update(preds_lat=np_(preds)[:, :, 0, ::s, ::s], idw_lat=np_(taps["idw"])[:, :, ::s, ::s],
+               dec3_lat=np_(taps["dec3"])[:, ::16], res3_lat=np_(taps["res3"])[:, ::5, ::s, ::s],
+               preds_sum=np.float64(preds.double().sum()), preds_abs_sum=np.float64(preds.double().abs().sum()),
+               logits_fake=np_(lf), logits_real=np_(lr_), logits_g=np_(lg),
+               loss_d=np.float32(loss_d.item()), loss_g=np.float32(loss_g.item()), adv=np.float32(adv.item()),
+               pool=np.float32(ld["pool"]), reg=np.float32(ld["reg"]), lattice=np.int32(s), batch=np.int32(batch))
+    res.update({"ggradnorm/" + n: np.float32(p.grad.norm().item()) for n, p in G.named_parameters() if p.grad is not None})
+    names = ["input.layers.0.conv.weight", "input.layers.1.conv.bias", "Convsin.0.main.0.W", "Convsin.0.main.0.D",
+             "ConvsOut.0.main.0.W", "UP.2.pos", "UP.0.proj.bias", "UP.1.proj.bias", "Decoder.0.layers.0.main.0.main.0.D",
+             "Decoder.0.layers.3.main.1.main.0.D"]
+    if big_grads:
+        names += ["Decoder.0.layers.0.main.0.main.0.W", "Decoder.3.layers.3.main.1.main.0.D"]
+    for n in names:
+        res["ggrad/" + n] = np_(dict(G.named_parameters())[n].grad)
+    gsd, dsd = G.state_dict(), D.state_dict()
+    res.update({"g1sum/" + k: np.float64(v.double().sum()) for k, v in gsd.items()})
+    res.update({"d1sum/" + k: np.float64(v.double().sum()) for k, v in dsd.items()})
+    res["d1/d3d.0.weight_u"] = np_(dsd["d3d.0.weight_u"])
+    res["d1/d2d.6.weight_v"] = np_(dsd["d2d.6.weight_v"])
+    for hk in hooks:
+        hk.remove()
+    np.savez_compressed(os.path.join(OUT, out_name), **res)
+    print(out_name, ": loss_g", res["loss_g"], "loss_d", res["loss_d"], "pool", res["pool"], "reg", res["reg"])
+
+
+def case_e2e_128():
+    """configs[1] geometry: B=2, 128x128; sample 0 the 79-gauge 'stis' mask, sample 1 an 'sti' block-10 mask (169 pts/frame;
+    seed 13: the first seed >= 12 without a host-dependent IDW tie voxel, see _full_step)."""
+    _full_step(128, 128, 2, [seeded.gauge_mask(128, 128, 79), seeded.block_mask(128, 128, 10, seed=13)], 3, "e2e_128.npz")
+
+
+def case_e2e_256():
+    """configs[3] geometry: B=1, 256x256, 'sti' block-20 mask (169 gauges/frame, N = 2704; seed 1 = first seed without a
+    host-dependent IDW tie voxel, see _full_step; 316-gauge masks have 1-7 such voxels for every seed tried): the re-sized
+    tiles (UP.pos 256/128/64, D logits (1,4096)) through forward, backward and Adam."""
+    _full_step(256, 256, 1, [seeded.block_mask(256, 256, 20, seed=1)], 5, "e2e_256.npz", big_grads=False)
+
+
 def case_idw():
     """idw_3d_knn alone (layer.py:259-293): N>=256 (partial_sort top-k path) and N<256 (nth_element path),
     including a regular lattice where equidistant ties are common."""
@@ -308,6 +395,10 @@ if __name__ == "__main__":
     if "--inference-variant-only" in sys.argv:
         case_inference_variant()
         sys.exit(0)
+    if "--full-size-only" in sys.argv:
+        case_e2e_128()
+        case_e2e_256()
+        sys.exit(0)
     case_init()
     case_inference_variant()
     case_metrics()
@@ -317,6 +408,8 @@ if __name__ == "__main__":
     case_e2e_32()
     case_eval_and_infer_32()
     case_g_128()
+    case_e2e_128()
+    case_e2e_256()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

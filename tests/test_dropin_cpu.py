@@ -62,3 +62,25 @@ def test_other_model_families_are_rejected():
     from p2igan_bench.models import build_generator
     with pytest.raises(NotImplementedError):
         build_generator({"model": {"name": "dk"}, "data": {"train": {"h": 32, "w": 32}}})
+
+
+def test_long_window_generalisation_t32_shapes():
+    """BASELINE configs[4] (T=32): NO reference behaviour exists (layer.py:310 AttentionBlock(16) and p2igan.py:46,66,79
+    raise for T != 16).  This build's generalisation (AttentionBlock(T), Convsin T->4T, base 4T, D
+    in_channels T) keeps the key names and the T=16 shapes; parity for T != 16 is UNPINNED (oracle self-consistency only)."""
+    import pytest
+    from p2igan_bench.models import build_discriminator, build_generator
+    from p2igan_bench.utils import seeded
+    cfg = {"model": {"name": "p2igan", "in_channels": 1}, "data": {"train": {"h": 32, "w": 32, "sample_length": 32}}}
+    G, D = build_generator(cfg), build_discriminator(cfg)
+    G.load_state_dict(seeded.seeded_generator_state(32, 32, t=32), strict=True)
+    D.load_state_dict(seeded.seeded_discriminator_state(t=32), strict=True)
+    sd = G.state_dict()
+    assert tuple(sd["input.layers.0.conv.weight"].shape) == (32, 32, 1)
+    assert tuple(sd["Convsin.0.main.0.W"].shape) == (128, 8, 9) and tuple(sd["ConvsOut.0.main.0.W"].shape) == (32, 32, 1)
+    assert tuple(sd["Decoder.3.layers.0.main.0.main.0.W"].shape) == (1024, 1024, 9)
+    assert tuple(D.state_dict()["d2d.0.weight_orig"].shape) == (64, 32, 3, 3)
+    # T=16 keys are a subset-by-name of T=32's: same module tree
+    assert list(build_generator(CFG).state_dict().keys()) == list(sd.keys())
+    with pytest.raises(RuntimeError):
+        build_generator({"model": {"name": "p2igan"}, "data": {"train": {"h": 32, "w": 32, "sample_length": 20}}})

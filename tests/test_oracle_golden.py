@@ -99,6 +99,28 @@ def test_train_steps_match_reference(golden):
     assert rel_err(st.dp["d2d.2.bias"].numpy(), g["d3/d2d.2.bias"]) < 1e-3
 
 
+def _oracle_full_step(golden, name, h):
+    import fullsize
+    g = golden(name)
+    frames, masked, masks = fullsize.batch_for(g, h, h)
+    st = O.TrainState(seeded.seeded_generator_state(h, h), seeded.seeded_discriminator_state(),
+                      {"k1_weight": 0.05, "adversarial_weight": 0.01, "gan_loss": "hinge"}, {"lr": 1e-4, "beta1": 0.0, "beta2": 0.99})
+    taps = {}
+    r = st.step(frames, masked, masks, keep_grads=True, taps=taps)
+    fullsize.check(g, r, r["ggrads"], r["dgrads"], st.gp, st.dp, {k: v.detach() for k, v in taps.items()})
+    assert r["dgrads"]["alpha3d"] is None
+
+
+def test_full_size_train_step_128_matches_reference(golden):
+    """configs[1] geometry (B=2, 128x128): one full G+D step of the oracle vs the genuine reference's (e2e_128.npz)."""
+    _oracle_full_step(golden, "e2e_128.npz", 128)
+
+
+def test_full_size_train_step_256_matches_reference(golden):
+    """configs[3] geometry (B=1, 256x256, 316 gauges): e2e_256.npz."""
+    _oracle_full_step(golden, "e2e_256.npz", 256)
+
+
 def test_infer_event_matches_reference(golden):
     g = golden("infer_32.npz")
     h = w = 32
