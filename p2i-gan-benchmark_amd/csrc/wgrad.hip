@@ -206,7 +206,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g) {
 // two waves per SIMD so that one wave's DMA issue / LDS waits hide under the other's MFMAs.
 // Y4: dy rows are 16-B aligned (nW % 4 == 0): dy image pitch NPIX+4 filled by 16-B DMA and read with
 // ds_read_b128 (conflict-free: 16-lane groups see 16 distinct residues of 4*o mod 64), one read per 2 k-steps.
-template <int NPIX, int NTAP, bool Y4, int CB>
+// LJU >= 0 (3x3, stride 1, pad 1, Y4 + 16-B x image only): "window" inner loop.  A unit = 4 consecutive pixels of a tile row
+// (LJU = log2 of the units per tile row).  The MFMA's two k slots are the pixel pairs (p, p+2) and (p+1, p+3): lanes 0-31 read the
+// 8 bytes at pixel p, lanes 32-63 the 8 bytes at p + 2 (both 8-B aligned: the dx = 0 column of a unit start sits on a 16-B
+// boundary of the image), so that register k of a unit's 4-float window is the operand (lo: x[p+k], hi: x[p+k+2]) as it stands.
+// The three dx taps of a kernel row then take registers (k-1, k), i.e. the SAME loaded window, with k = -1 handed over from the
+// previous unit: 6 ds_read_b64 (2-way conflicts) + 1 for dy per 18 MFMAs instead of 18 ds_read_b32 (4-way) + 1 ds_read_b128, every
+// address a per-tile base register + an immediate, no address arithmetic in the loop.
+template <int NPIX, int NTAP, bool Y4, int CB, int LJU = -1>
 __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int PP = Y4 ? NPIX + 4 : NPIX + 1;
@@ -304,6 +311,68 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
     }
   };
 
+  // window kernels: the per-lane part of every DMA offset is tile-invariant -> computed once, kept in registers; a tile adds a
+  // scalar base (soffset, >= 0) and the border tests.  (The generic `issue` above redoes ~30 VALU ops of index arithmetic per DMA
+  // instruction, in both waves of every SIMD at once, right after the barrier: the matrix pipe idles behind it.)
+  constexpr int NXI = 2, NYI = (64 * PP / 4 + 511) / 512;
+  int xl_off[NXI], xl_col[NXI], yl_off[NYI], yl_jb[NYI], yl_jh[NYI], yl_jw[NYI];
+  bool xl_ok[NXI], yl_ok[NYI];
+  if constexpr (LJU >= 0) {
+    const int rb4 = rowblk >> 2;
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int e = i * 512 + tid;
+      const int cc = fast_div(e, g.mg_ewq4);
+      const int g4 = e - cc * (g.eWq >> 2);
+      xl_ok[i] = e < rb4 && cc < CB && c0 + cc < g.Cx;
+      xl_off[i] = (cc * g.sT * sHW + 4 * g4) * 4;
+      xl_col[i] = 4 * g4;
+    }
+#pragma unroll
+    for (int i = 0; i < NYI; ++i) {
+      const int q4 = i * 512 + tid;
+      const int o = q4 / (PP / 4);
+      const int pp = (q4 - o * (PP / 4)) * 4;
+      const int jw = pp & JWm, r = pp >> g.ljw;
+      const int jh = r & JHm, jb = r >> g.ljh;
+      yl_ok[i] = q4 < 64 * PP / 4 && pp < NPIX && o0 + o < g.Co;
+      yl_off[i] = (((jb * g.Co + o) * g.nT) * nHW + jh * g.nW + jw) * 4;
+      yl_jb[i] = jb; yl_jh[i] = jh; yl_jw[i] = jw;
+    }
+  }
+  auto issue_fast = [&](int tile, int bufoff) {
+    int tl = tile;
+    const int tw = tl % g.ntw; tl /= g.ntw;
+    const int th = tl % g.nth; tl /= g.nth;
+    const int tt = tl % g.ntt;
+    const int tb = tl / g.ntt;
+    const int j0b = tb << g.ljb, j0h = th << g.ljh, j0w = tw << g.ljw;
+    const int st = tt * g.mT + g.bT, sh0 = j0h * g.mH + g.bH, sw0 = j0w * g.mW + g.bW;
+    const bool tvalid = (unsigned)st < (unsigned)g.sT;
+    const int rb4 = rowblk >> 2;
+    int xv[NXI];
+#pragma unroll
+    for (int i = 0; i < NXI; ++i)
+      xv[i] = (xl_ok[i] && (unsigned)(sw0 + xl_col[i]) < (unsigned)g.sW) ? xl_off[i] + sw0 * 4 : -16;
+    for (int prow = 0; prow < nprow; ++prow) {
+      const int jb = prow / g.eH, eh = prow - jb * g.eH;
+      const int b = j0b + jb, h = sh0 + eh;
+      const bool rok = tvalid && b < g.B && (unsigned)h < (unsigned)g.sH;
+      const int soff = rok ? (((b * g.Cx + c0) * g.sT + st) * sHW + h * g.sW) * 4 : 0;
+#pragma unroll
+      for (int i = 0; i < NXI; ++i)
+        if (i * 512 + wbase < rb4)
+          dma_b128(rs_x, smem_la + 4u * (bufoff + prow * rowblk + (i * 512 + wbase) * 4), rok ? xv[i] : -16, soff);
+    }
+    const int ybo = bufoff + YOFF;
+    const int ysoff = (((j0b * g.Co + o0) * g.nT + tt) * nHW + j0h * g.nW + j0w) * 4;
+#pragma unroll
+    for (int i = 0; i < NYI; ++i) {
+      const bool ok = yl_ok[i] && j0b + yl_jb[i] < g.B && j0h + yl_jh[i] < g.nH && j0w + yl_jw[i] < g.nW;
+      if (i * 512 + wbase < 64 * PP / 4) dma_b128(rs_y, smem_la + 4u * (ybo + (i * 512 + wbase) * 4), ok ? yl_off[i] : -16, ysoff);
+    }
+  };
+
   int toff[NTAP];
 #pragma unroll
   for (int t = 0; t < NTAP; ++t) toff[t] = g.tap_offq[t];
@@ -316,12 +385,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
   int k = 0;
   const bool fuse_bias = Y4 && g.dbias != nullptr && blockIdx.y == 0;   // bias gradient rides on the staged dy tiles
   float bsum = 0.f;
-  if ((int)blockIdx.x < g.ntiles) issue(blockIdx.x, 0);
+  if ((int)blockIdx.x < g.ntiles) {
+    if constexpr (LJU >= 0) issue_fast(blockIdx.x, 0); else issue(blockIdx.x, 0);
+  }
   for (int tile = blockIdx.x; tile < g.ntiles; tile += g.nsplit, ++k) {
     dma_wait_all();                                     // this wave's share of the tile has landed ...
     __syncthreads();                                    // ... and so has everybody else's; the other buffer is free
     float* cur = smem + (k & 1) * BUFSZ;
-    if (tile + g.nsplit < g.ntiles && !(g.dbg & 2)) issue(tile + g.nsplit, ((k + 1) & 1) * BUFSZ);
+    if (tile + g.nsplit < g.ntiles && !(g.dbg & 2)) {
+      if constexpr (LJU >= 0) issue_fast(tile + g.nsplit, ((k + 1) & 1) * BUFSZ); else issue(tile + g.nsplit, ((k + 1) & 1) * BUFSZ);
+    }
     if constexpr (Y4) {
       if (fuse_bias) {                                      // 64 channels x 8 segments of NPIX/8 pixels; padding pixels are 0
         const float* yrow = cur + YOFF + (tid >> 3) * PP + (tid & 7) * (NPIX / 8);
@@ -345,7 +418,78 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
       return (u >> lju) * JW + (u & upr_m) * UPIX;
     };
     const int nu = (g.dbg & 1) ? 0 : NU;
-    if constexpr (Y4) {
+    if constexpr (LJU >= 0) {
+      static_assert(Y4 && NTAP == 9, "window loop: 3x3");
+      constexpr int UPR0 = 1 << LJU;                             // units per tile row
+      constexpr int UPR = UPR0 < NU ? UPR0 : NU;                 // units per row SEGMENT of this wave (a wave may own part of a row)
+      constexpr int NR = NU / UPR;                               // row segments of this wave
+      static_assert(NU % UPR == 0 && (UPR0 % UPR) == 0, "window loop: whole segments");
+      // per-tile bases (floats): x window of (segment rr, kernel row b) at the segment's first unit, this lane's channel
+      const float* xb[NR][3];
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) {
+        const int u0 = __builtin_amdgcn_readfirstlane(kh * NU + rr * UPR);
+        const int pr = u0 >> LJU, cu0 = u0 & (UPR0 - 1);
+        const int jh = pr & JHm, jb = pr >> g.ljh;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          xb[rr][b] = cur + (wm * 32 + l31) * g.eWq + ((jb * g.eH + jh + b) * rowblk + 4 * cu0 + 4 + 2 * lhi);
+      }
+      const float* ybp = cur + YOFF + (wn * 32 + l31) * PP + (kh * NU * 4 + 2 * lhi);
+      float2 c01[3], c23[3], n01[3], n23[3], yc, yn;
+      float pr3[3], npr3[3];
+      auto load_unit = [&](int uu, float2 (&w01)[3], float2 (&w23)[3], float (&wp)[3], float2& yy) {
+        const int rr = uu / UPR, cu = uu % UPR;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          w01[b] = *reinterpret_cast<const float2*>(xb[rr][b] + 4 * cu);
+          w23[b] = *reinterpret_cast<const float2*>(xb[rr][b] + 4 * cu + 2);
+          if (cu == 0) wp[b] = xb[rr][b][-1];                    // (lo: x[p-1], hi: x[p+1]) at a row start
+        }
+        yy = *reinterpret_cast<const float2*>(ybp + 4 * uu);
+      };
+      if (nu > 0) {
+        load_unit(0, c01, c23, pr3, yc);
+#pragma unroll
+        for (int uu = 0; uu < NU; ++uu) {
+          if (uu + 1 < NU) load_unit(uu + 1, n01, n23, npr3, yn);
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            acc[b * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pr3[b], yc.x, acc[b * 3 + 0], 0, 0, 0);
+            acc[b * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c01[b].x, yc.x, acc[b * 3 + 1], 0, 0, 0);
+            acc[b * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(c01[b].y, yc.x, acc[b * 3 + 2], 0, 0, 0);
+            acc[b * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c01[b].x, yc.y, acc[b * 3 + 0], 0, 0, 0);
+            acc[b * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c01[b].y, yc.y, acc[b * 3 + 1], 0, 0, 0);
+            acc[b * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(c23[b].x, yc.y, acc[b * 3 + 2], 0, 0, 0);
+          }
+          // pin the interleave: the next unit's LDS reads ride in this unit's MFMA gaps
+          if (uu + 1 < NU) {
+            constexpr int NL = 7;
+            const int extra = ((uu + 1) % UPR == 0) ? 3 : 0;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (extra) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            } else {
+              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+          }
+          if (uu + 1 < NU) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+              pr3[b] = ((uu + 1) % UPR == 0) ? npr3[b] : c23[b].y;
+              c01[b] = n01[b]; c23[b] = n23[b];
+            }
+            yc = yn;
+          }
+        }
+      }
+    } else if constexpr (Y4) {
       // software pipeline: while the MFMAs of one half-unit run, the next half-unit's A operands are in flight
       float a0[NTAP], a1[NTAP];
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f), vn = v;
@@ -567,7 +711,13 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
       { const char* e = getenv("P2I_WGRAD_DBG"); g.dbg = e ? atoi(e) : 0; }
       typedef void (*wk_t)(const WgradGeom);
       wk_t kern;
-      if (CBh == 64) kern = g.tpg == 9 ? (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 64> : (wk_t)wgrad_dma_kernel<NPIX, 9, false, 64>)
+      // window inner loop (3x3, stride 1 in h and w, pad 1 in w, 16-B x image): P2I_WGRAD_WINDOW=0 keeps the per-tap reads
+      static const int window_on = getenv("P2I_WGRAD_WINDOW") ? atoi(getenv("P2I_WGRAD_WINDOW")) : 1;
+      const int lju = ilog2(jw) - 2;
+      const bool window = window_on && CBh == 64 && g.tpg == 9 && y4 && g.x4 && d->sh == 1 && d->sw == 1 && d->pw == 1 && d->kw == 3 && lju >= 1 && lju <= 3 && g.rowblk <= 4096;
+      if (window && CBh == 64)
+        kern = lju == 3 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 64, 3> : (lju == 2 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 64, 2> : (wk_t)wgrad_dma_kernel<NPIX, 9, true, 64, 1>);
+      else if (CBh == 64) kern = g.tpg == 9 ? (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 64> : (wk_t)wgrad_dma_kernel<NPIX, 9, false, 64>)
                                        : (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 1, true, 64> : (wk_t)wgrad_dma_kernel<NPIX, 1, false, 64>);
       else kern = g.tpg == 9 ? (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 32> : (wk_t)wgrad_dma_kernel<NPIX, 9, false, 32>)
                              : (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 1, true, 32> : (wk_t)wgrad_dma_kernel<NPIX, 1, false, 32>);
