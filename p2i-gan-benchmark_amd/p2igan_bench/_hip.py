@@ -82,7 +82,8 @@ def load():
         raise RuntimeError(
             f"libp2i_hip.so not found at {_LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C p2i-gan-benchmark_amd/csrc`.  There is no CPU fallback for the product path.")
-    lib = C.CDLL(_LIB_PATH)
+    # P2I_HIP_LIB: another build of the SAME library (kernel A/B experiments, tools/); never a different backend
+    lib = C.CDLL(os.environ.get("P2I_HIP_LIB") or _LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
