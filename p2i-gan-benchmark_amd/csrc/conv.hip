@@ -434,6 +434,10 @@ extern "C" int p2i_conv_fwd(const p2i_conv_desc* d, const float* x, const float*
                             const float* residual, float* y, int act, void* stream) {
   if (int e = check_desc(d)) return e;
   P2I_REQUIRE(x && wp && y, "null pointer");
+  if (d->Cin == 1 && residual == nullptr && x6_ctx().wb == nullptr) {         // single-channel input: dedicated kernel (conv_c1.hip)
+    const int rc = c1_fwd(d, x, wp, bias, y, act, (hipStream_t)stream);
+    if (rc != 1) { g_last_plan[0] = 32; g_last_plan[1] = 64; g_last_plan[2] = 1; g_last_plan[3] = 2; g_last_plan[4] = 27; g_last_plan[5] = 1; return rc; }
+  }
   PatchGeom g{};
   g.src = x; g.src_y = nullptr; g.wp = wp; g.bias = bias; g.res = residual; g.dst = y; g.act_epi = act; g.act_pro = P2I_ACT_NONE;
   g.B = d->B; g.Ck = d->Cin; g.Cm = d->Cout; g.CmPad = (d->Cout + 31) / 32 * 32;

@@ -109,8 +109,18 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const p2i_conv_desc d, co
   }
 }
 
+static bool c1_shape_ok(const p2i_conv_desc* d);
+static int c1_dgrad_fast(const p2i_conv_desc* d, const float* dy, const float* wp_d, const float* add, const float* mask_y, int mask_act,
+                         float* dx, hipStream_t s);
+static int c1_wgrad_mfma(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* dbias, hipStream_t s);
+static const int c1_fast_on = getenv("P2I_C1_FAST") ? atoi(getenv("P2I_C1_FAST")) : 1;
+
 int c1_dgrad(const p2i_conv_desc* d, const float* dy, const float* wp_d, const float* add, const float* mask_y, int mask_act,
              float* dx, hipStream_t s) {
+  if (c1_fast_on && c1_shape_ok(d)) {
+    const int rc = c1_dgrad_fast(d, dy, wp_d, add, mask_y, mask_act, dx, s);
+    if (rc != 1) return rc;
+  }
   const int ntaps = d->kt * d->kh * d->kw;
   const size_t total = (size_t)d->B * d->Ti * d->Hi * d->Wi;
   const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
@@ -119,6 +129,10 @@ int c1_dgrad(const p2i_conv_desc* d, const float* dy, const float* wp_d, const f
 }
 
 int c1_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* dbias, hipStream_t s) {
+  if (c1_fast_on && c1_shape_ok(d)) {
+    const int rc = c1_wgrad_mfma(d, x, dy, dwp, dbias, s);
+    if (rc != 1) return rc;
+  }
   constexpr int NPW = 32;
   const int ntw = ceil_div(d->Wo, NPW), nth = (d->Ho + 1) / 2;
   const int ntiles = d->B * d->To * nth * ntw;
@@ -126,6 +140,358 @@ int c1_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp
   const size_t lds = sizeof(float) * ((size_t)d->kt * eH * eW + (size_t)d->Cout * (2 * NPW + 1));
   const int grid = ntiles < 1024 ? ntiles : 1024;
   hipLaunchKernelGGL(c1_wgrad_kernel<NPW>, dim3(grid), dim3(256), lds, s, *d, x, dy, dwp, dbias, ntw, ntiles);
+  return launch_status();
+}
+
+}  // namespace p2i
+
+// =====================================================================================================================
+// Fast paths for THE layer these cases come from: Conv3d(1, Cout <= 32, k 3x3x3, stride (1,2,2), pad 1) (p2igan.py:133).
+// All three directions are HBM-bound (x is 1/8 of y): forward and weight gradient put the 27 taps on the MFMA's K / M side
+// (one 32x32 tile: taps x channels), the data gradient is a VALU stencil over 2x2x4 output blocks.
+// =====================================================================================================================
+namespace p2i {
+
+static bool c1_shape_ok(const p2i_conv_desc* d) {
+  return d->Cin == 1 && d->Cout <= 32 && d->kt == 3 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 2 && d->sw == 2 &&
+         d->pt == 1 && d->ph == 1 && d->pw == 1;
+}
+
+constexpr int C1_ROWS = 4, C1_TW = 64, C1_EH = 2 * C1_ROWS + 1, C1_EW = 2 * C1_TW + 1;      // output tile and its x patch (odd pitch)
+
+// x patch [3][EH][EW] of output tile (b, to, h0.., w0..): x[b, to-1+a, 2*h0-1+yy, 2*w0-1+xx], zero outside.  Split into
+// "all loads to registers" and "all LDS stores" (fixed trip count) so that the 14 loads of a thread are in flight together and
+// can be issued a tile ahead; the load is unconditional (clamped address) and the select follows it: a load under a per-element
+// condition makes hipcc branch around it and wait for each one separately.
+// Thread (g = tid >> 7, col = tid & 127) loads column `col` of the patch rows g*14 .. g*14+13 (27 rows = 3 frames x 9 rows; row
+// validity is wave-uniform, the column test a per-thread constant: no div/mod in the loop); column 128 of row r is loaded by
+// thread r.  (Index arithmetic with e % 129, e / 129 % 9 ... per element cost more VALU time than the whole tile's MFMAs.)
+constexpr int C1_NXE = 15;
+__device__ __forceinline__ void c1_load_x(const p2i_conv_desc& d, const float* __restrict__ x, float (&xr)[C1_NXE], int b, int to, int h0, int w0) {
+  const int HWi = d.Hi * d.Wi;
+  const int g = threadIdx.x >> 7, col = threadIdx.x & 127;
+  const int w = 2 * w0 - 1 + col;
+  const bool wok = (unsigned)w < (unsigned)d.Wi;
+  const float* xb = x + (size_t)b * d.Ti * HWi;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    const int r = g * 14 + i;                          // patch row (a, yy); r = 27 does not exist
+    const int a = r / C1_EH, yy = r - a * C1_EH;
+    const int t = to - 1 + a, h = 2 * h0 - 1 + yy;
+    const bool ok = r < 27 && wok && (unsigned)t < (unsigned)d.Ti && (unsigned)h < (unsigned)d.Hi;
+    const float v = xb[ok ? t * HWi + h * d.Wi + w : 0];
+    xr[i] = ok ? v : 0.f;
+  }
+  {                                                    // last column (xx = 128) of row tid
+    const int r = threadIdx.x, a = r / C1_EH, yy = r - a * C1_EH;
+    const int t = to - 1 + a, h = 2 * h0 - 1 + yy, wl = 2 * w0 - 1 + 128;
+    const bool ok = r < 27 && (unsigned)wl < (unsigned)d.Wi && (unsigned)t < (unsigned)d.Ti && (unsigned)h < (unsigned)d.Hi;
+    const float v = xb[ok ? t * HWi + h * d.Wi + wl : 0];
+    xr[14] = ok ? v : 0.f;
+  }
+}
+__device__ __forceinline__ void c1_store_x(float* sx, const float (&xr)[C1_NXE]) {
+  const int g = threadIdx.x >> 7, col = threadIdx.x & 127;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    const int r = g * 14 + i;
+    if (r < 27) sx[r * C1_EW + col] = xr[i];
+  }
+  if (threadIdx.x < 27) sx[threadIdx.x * C1_EW + 128] = xr[14];
+}
+
+// forward: y[b,o,to,ho,wo] = act(bias[o] + sum_tap w[o][tap] * patch).  MFMA: A = weights (M = o, K = tap: 14 steps of 2),
+// B = patch gather (N = 32 output columns).  Wave = one output row of the tile (2 x 32 columns).
+__global__ __launch_bounds__(256) void c1_fwd_kernel(const p2i_conv_desc d, const float* __restrict__ x, const float* __restrict__ wp,
+                                                    const float* __restrict__ bias, float* __restrict__ y, int act, int nth, int ntw, int ntiles) {
+  __shared__ float sx[3 * C1_EH * C1_EW + 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+  float wa[14];
+  int toff[14];
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    const int tap = 2 * s + lhi;
+    wa[s] = (tap < 27 && l31 < d.Cout) ? wp[tap * 32 + l31] : 0.f;          // packed [tap][Cin = 1][32]
+    const int tp = tap < 27 ? tap : 26;
+    toff[s] = ((tp / 9) * C1_EH + (tp / 3) % 3) * C1_EW + tp % 3;
+  }
+  float bo[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    bo[r] = (bias && o < d.Cout) ? bias[o] : 0.f;
+  }
+  const size_t HWo = (size_t)d.Ho * d.Wo;
+  auto decode = [&](int tile, int& b, int& to, int& h0, int& w0) {
+    const int tw = tile % ntw; tile /= ntw;
+    const int th = tile % nth; tile /= nth;
+    to = tile % d.To; b = tile / d.To;
+    h0 = th * C1_ROWS; w0 = tw * C1_TW;
+  };
+  float xr[C1_NXE];
+  int b, to, h0, w0;
+  if ((int)blockIdx.x < ntiles) { decode(blockIdx.x, b, to, h0, w0); c1_load_x(d, x, xr, b, to, h0, w0); }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    decode(tile, b, to, h0, w0);
+    __syncthreads();                                   // everybody is done reading the previous patch
+    c1_store_x(sx, xr);
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) {              // next tile's patch travels while this one is multiplied and stored
+      int nb_, nto, nh0, nw0;
+      decode(tile + gridDim.x, nb_, nto, nh0, nw0);
+      c1_load_x(d, x, xr, nb_, nto, nh0, nw0);
+    }
+    const int ho = h0 + wave;
+    if (ho >= d.Ho) continue;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int q = nb * 32 + l31;
+      const float* xp = sx + (2 * wave) * C1_EW + 2 * q;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = bo[r];
+#pragma unroll
+      for (int s = 0; s < 14; ++s) {
+        float bv = xp[toff[s]];
+        if (s == 13) bv = lhi ? 0.f : bv;                                    // tap 27 does not exist (0 * inf guard)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], bv, acc, 0, 0, 0);
+      }
+      const int wo = w0 + q;
+      if (wo < d.Wo) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (o < d.Cout) y[(((size_t)b * d.Cout + o) * d.To + to) * HWo + (size_t)ho * d.Wo + wo] = act_apply(acc[r], act);
+        }
+      }
+    }
+  }
+}
+
+// data gradient: thread = 4 frames x 2 x 2 pixels of dx (one output-parity quad per frame).  Per dy channel: 6 frames x 2 x 2 dy
+// values feed 108 FMAs with the channel's 27 weights (LDS broadcast).  dx = (sum + add) * act'(mask).
+__global__ __launch_bounds__(256) void c1_dgrad_fast_kernel(const p2i_conv_desc d, const float* __restrict__ dy, const float* __restrict__ wp_d,
+                                                           const float* __restrict__ add, const float* __restrict__ mask_y, int mask_act,
+                                                           float* __restrict__ dx, int nJ, int nI, int nTB) {
+  __shared__ float sw[32 * 28];
+  for (int i = threadIdx.x; i < 27 * d.Cout; i += 256) {
+    const int tap = i / d.Cout, o = i % d.Cout;
+    sw[o * 28 + tap] = wp_d[(size_t)i * 32];                                  // packed [tap][Cout][32], input channel 0
+  }
+  __syncthreads();
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int j = (int)(gid % nJ);
+  long long rest = gid / nJ;
+  const int i = (int)(rest % nI); rest /= nI;
+  const int tb = (int)(rest % nTB);
+  const int b = (int)(rest / nTB);
+  if (b >= d.B) return;
+  const int t0 = 4 * tb;
+  const size_t HWo = (size_t)d.Ho * d.Wo, cs = (size_t)d.To * HWo;
+  // dy addresses of the 6 x 2 x 2 block (clamped) and their validity
+  int goff[6][2][2];
+  bool gok[6][2][2];
+#pragma unroll
+  for (int f = 0; f < 6; ++f)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int to = t0 - 1 + f, ho = i + r, wo = j + q;
+        gok[f][r][q] = (unsigned)to < (unsigned)d.To && ho < d.Ho && wo < d.Wo;
+        goff[f][r][q] = gok[f][r][q] ? (int)((size_t)to * HWo + (size_t)ho * d.Wo + wo) : 0;
+      }
+  float acc[4][2][2];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[tt][p >> 1][p & 1] = 0.f;
+  const float* gb = dy + (size_t)b * d.Cout * cs;
+  // channel o + 1's 24 loads are issued before channel o's 108 FMAs (unconditional loads at clamped offsets, masked after)
+  float G[6][2][2], Gn[6][2][2];
+#pragma unroll
+  for (int f = 0; f < 6; ++f)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) G[f][r][q] = gb[goff[f][r][q]];
+  for (int o = 0; o < d.Cout; ++o) {
+    const float* gn = gb + (size_t)(o + 1 < d.Cout ? o + 1 : o) * cs;
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) Gn[f][r][q] = gn[goff[f][r][q]];
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) G[f][r][q] = gok[f][r][q] ? G[f][r][q] : 0.f;
+    const float* w = sw + o * 28;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      // kernel rows / columns reaching an even (ph = 0) pixel: bb = 1 (ho = i); an odd one: bb = 0 (ho = i + 1), bb = 2 (ho = i)
+      const float w00 = w[a * 9 + 0], w01 = w[a * 9 + 1], w02 = w[a * 9 + 2];
+      const float w10 = w[a * 9 + 3], w11 = w[a * 9 + 4], w12 = w[a * 9 + 5];
+      const float w20 = w[a * 9 + 6], w21 = w[a * 9 + 7], w22 = w[a * 9 + 8];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int f = tt + 2 - a;
+        acc[tt][0][0] += w11 * G[f][0][0];
+        acc[tt][0][1] += w10 * G[f][0][1] + w12 * G[f][0][0];
+        acc[tt][1][0] += w01 * G[f][1][0] + w21 * G[f][0][0];
+        acc[tt][1][1] += w00 * G[f][1][1] + w02 * G[f][1][0] + w20 * G[f][0][1] + w22 * G[f][0][0];
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) G[f][r][q] = Gn[f][r][q];
+  }
+  const size_t HWi = (size_t)d.Hi * d.Wi;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int t = t0 + tt;
+    if (t >= d.Ti) break;
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      const int h = 2 * i + ph;
+      if (h >= d.Hi) continue;
+#pragma unroll
+      for (int pw = 0; pw < 2; ++pw) {
+        const int w = 2 * j + pw;
+        if (w >= d.Wi) continue;
+        const size_t idx = ((size_t)b * d.Ti + t) * HWi + (size_t)h * d.Wi + w;
+        float v = acc[tt][ph][pw];
+        if (add) v += add[idx];
+        if (mask_y) v = act_grad(v, mask_y[idx], mask_act);
+        dx[idx] = v;
+      }
+    }
+  }
+}
+
+// weight (+ bias) gradient: one 32x32 MFMA tile, rows = taps (row 27 = bias: A operand 1.0), columns = dy channels, K = output
+// positions.  Persistent workgroups over (b, to, 4 rows x 64 columns) tiles; wave = one tile row; per-wave partial tiles are
+// summed through LDS and added to dwp / dbias with one float atomic per element per workgroup (256-B segments: full rate).
+__global__ __launch_bounds__(256) void c1_wgrad_mfma_kernel(const p2i_conv_desc d, const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* dwp, float* dbias, int nth, int ntw, int ntiles) {
+  constexpr int PP = C1_ROWS * C1_TW + 4;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sx = sm;                                        // [3][EH][EW] + {1, 0}
+  float* sy = sm + ((3 * C1_EH * C1_EW + 2 + 3) & ~3);   // [32][PP]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+  if (threadIdx.x == 0) { sx[3 * C1_EH * C1_EW] = 1.f; sx[3 * C1_EH * C1_EW + 1] = 0.f; }
+  // A operand address of this lane: tap row l31 (27: the constant 1, 28..31: the constant 0)
+  const int tap = l31;
+  const int aoff = tap < 27 ? ((tap / 9) * C1_EH + (tap / 3) % 3 + 2 * wave) * C1_EW + tap % 3 + 2 * lhi : 3 * C1_EH * C1_EW + (tap == 27 ? 0 : 1);
+  const int astep = tap < 27 ? 4 : 0;
+  const int boff = l31 * PP + wave * C1_TW + lhi;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const size_t HWo = (size_t)d.Ho * d.Wo;
+  const bool v4 = (d.Wo & 3) == 0;
+  constexpr int NYE = 32 * C1_ROWS * (C1_TW / 4) / 256;                      // float4 of the dy tile per thread
+  float xr[C1_NXE];
+  float4 yr[NYE];
+  auto load_tile = [&](int tile) {
+    const int tw = tile % ntw; tile /= ntw;
+    const int th = tile % nth; tile /= nth;
+    const int to = tile % d.To, b = tile / d.To;
+    const int h0 = th * C1_ROWS, w0 = tw * C1_TW;
+    c1_load_x(d, x, xr, b, to, h0, w0);
+#pragma unroll
+    for (int i = 0; i < NYE; ++i) {                                          // dy tile [o][row][64], zero outside / for o >= Cout
+      const int e = i * 256 + threadIdx.x;
+      const int q4 = e % (C1_TW / 4), r = (e / (C1_TW / 4)) % C1_ROWS, o = e / (C1_TW / 4 * C1_ROWS);
+      const int ho = h0 + r, wo = w0 + 4 * q4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = o < d.Cout && ho < d.Ho && wo < d.Wo;
+      const float* src = dy + (ok ? (((size_t)b * d.Cout + o) * d.To + to) * HWo + (size_t)ho * d.Wo + wo : 0);
+      if (v4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(src);             // unconditional, then masked (see c1_load_x)
+        if (ok) v = t4;
+      } else if (ok) {
+        v.x = src[0]; if (wo + 1 < d.Wo) v.y = src[1]; if (wo + 2 < d.Wo) v.z = src[2]; if (wo + 3 < d.Wo) v.w = src[3];
+      }
+      yr[i] = v;
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    c1_store_x(sx, xr);
+#pragma unroll
+    for (int i = 0; i < NYE; ++i) {
+      const int e = i * 256 + threadIdx.x;
+      const int q4 = e % (C1_TW / 4), r = (e / (C1_TW / 4)) % C1_ROWS, o = e / (C1_TW / 4 * C1_ROWS);
+      *reinterpret_cast<float4*>(sy + o * PP + r * C1_TW + 4 * q4) = yr[i];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);         // in flight during the MFMAs below
+    const float* ap = sx + aoff;
+    const float* bp = sy + boff;
+#pragma unroll 8
+    for (int q = 0; q < C1_TW; q += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(q >> 1) * astep], bp[q], acc, 0, 0, 0);
+  }
+  // sum the four waves' tiles, then one atomic per element
+  __syncthreads();
+  float* red = sm;                                       // 4 x 16 x 64 floats
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = (red[r * 64 + lane] + red[(16 + r) * 64 + lane]) + (red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane]);
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;     // tap
+      if (l31 < d.Cout) {
+        if (row < 27) atomicAdd(dwp + row * 32 + l31, v);   // packed [tap][Cin = 1][32]
+        else if (row == 27 && dbias) atomicAdd(dbias + l31, v);
+      }
+    }
+  }
+}
+
+int c1_fwd(const p2i_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, hipStream_t s) {
+  if (!c1_fast_on || !c1_shape_ok(d)) return 1;
+  const int nth = ceil_div(d->Ho, C1_ROWS), ntw = ceil_div(d->Wo, C1_TW);
+  const long long ntiles = (long long)d->B * d->To * nth * ntw;
+  if (ntiles > 0x7fffffff) return 1;
+  const int grid = (int)ntiles;                               // (the kernel loops; > 1 tile per workgroup measured slower)
+  hipLaunchKernelGGL(c1_fwd_kernel, dim3(grid), dim3(256), 0, s, *d, x, wp, bias, y, act, nth, ntw, (int)ntiles);
+  return launch_status();
+}
+
+static int c1_dgrad_fast(const p2i_conv_desc* d, const float* dy, const float* wp_d, const float* add, const float* mask_y, int mask_act,
+                         float* dx, hipStream_t s) {
+  const int nJ = (d->Wi + 1) / 2, nI = (d->Hi + 1) / 2, nTB = (d->Ti + 3) / 4;
+  const long long nthr = (long long)d->B * nTB * nI * nJ;
+  if ((long long)d->To * d->Ho * d->Wo >= (1ll << 31)) return 1;
+  hipLaunchKernelGGL(c1_dgrad_fast_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, *d, dy, wp_d, add, mask_y, mask_act, dx,
+                     nJ, nI, nTB);
+  return launch_status();
+}
+
+static int c1_wgrad_mfma(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* dbias, hipStream_t s) {
+  const int nth = ceil_div(d->Ho, C1_ROWS), ntw = ceil_div(d->Wo, C1_TW);
+  const long long ntiles = (long long)d->B * d->To * nth * ntw;
+  if (ntiles > 0x7fffffff) return 1;
+  constexpr int PP = C1_ROWS * C1_TW + 4;
+  const size_t lds = sizeof(float) * (((3 * C1_EH * C1_EW + 2 + 3) & ~3) + 32 * PP);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)c1_wgrad_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_set = true;
+  }
+  const int grid = ntiles < 512 ? (int)ntiles : 512;
+  hipLaunchKernelGGL(c1_wgrad_mfma_kernel, dim3(grid), dim3(256), lds, s, *d, x, dy, dwp, dbias, nth, ntw, (int)ntiles);
   return launch_status();
 }
 

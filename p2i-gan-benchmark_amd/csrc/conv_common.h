@@ -149,5 +149,7 @@ int run_patch_gemm_fused(PatchGeom g, const ClassSpec* css, int ncls, int* plan6
 int c1_dgrad(const p2i_conv_desc* d, const float* dy, const float* wp_d, const float* add, const float* mask_y, int mask_act,
              float* dx, hipStream_t s);
 int c1_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* dbias, hipStream_t s);
+// forward of the same layer; returns 1 when the shape is not the (3x3x3, stride (1,2,2), pad 1) one
+int c1_fwd(const p2i_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, hipStream_t s);
 
 }  // namespace p2i

@@ -40,6 +40,8 @@ CONV_CASES = [
     ("dense_in16", 2, 2, 16, 64, (16, 16), (3, 3), (1, 1), (1, 1), "none", False, False),
     ("out_tanh", 2, 2, 64, 16, (16, 16), (1, 1), (1, 1), (0, 0), "tanh", False, False),
     ("d3d_first", 3, 2, 1, 32, (8, 16, 16), (3, 3, 3), (1, 2, 2), (1, 1, 1), "leaky", True, False),
+    ("d3d_first_tiles", 3, 2, 1, 32, (8, 40, 136), (3, 3, 3), (1, 2, 2), (1, 1, 1), "leaky", True, False),   # 2 column tiles, partial rows
+    ("d3d_first_odd", 3, 1, 1, 20, (5, 17, 22), (3, 3, 3), (1, 2, 2), (1, 1, 1), "leaky", True, False),       # T % 4 != 0, odd H, Cout < 32
     ("d3d_mid", 3, 2, 32, 64, (4, 16, 16), (3, 3, 3), (1, 2, 2), (1, 1, 1), "leaky", True, False),
     ("d3d_tstride", 3, 2, 16, 16, (8, 8, 8), (3, 3, 3), (2, 1, 1), (1, 1, 1), "leaky", True, False),
     ("d3d_1x1x1", 3, 2, 128, 1, (4, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0), "none", True, False),
