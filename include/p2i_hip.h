@@ -134,6 +134,12 @@ int p2i_weight_unpack_grad_batched(const float* const* dwp_f, const int* O, cons
                                    const float* const* w_orig, const float* const* sigma, const float* const* u,
                                    const float* const* v, float* dots, float* const* dw, int n, void* stream);
 
+/* p2i_weight_unpack_grad_batched with accumulate != 0: dw += ... (the discriminator's second backward pass of a D step adds to
+ * the first one's gradient: train.py:264-283 calls D twice before loss_d.backward()) */
+int p2i_weight_unpack_grad_batched_acc(const float* const* dwp_f, const int* O, const int* I, const int* ntaps,
+                                       const float* const* w_orig, const float* const* sigma, const float* const* u,
+                                       const float* const* v, float* dots, float* const* dw, int n, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------ spectral norm
  * One power iteration of torch.nn.utils.spectral_norm (call sites layer.py:402-407,
  * p2igan.py:141): v <- normalize(W^T u), u <- normalize(W v), sigma = u^T W v, eps 1e-12.
@@ -197,8 +203,10 @@ int p2i_dtail_bwd(const float* out2d, const float* alpha2d, const float* dfused,
  * scratch >= B*(T-1)*HW + 4096 floats. */
 int p2i_recloss(const float* pred, const float* target, float k1_alpha, float* out3, float* dpred,
                 float* scratch, int B, int T, int HW, void* stream);
-/* Hinge / lsgan losses (losses.py:210-226) with gradients.  mode: 0 = discriminator
- * (0.5*(L(real)+L(fake)), train.py:266-283), 1 = generator (-mean * weight, train.py:301-308). */
+/* Hinge / lsgan / nsgan losses (losses.py:210-226) with gradients; loss_type 0 hinge, 1 lsgan (MSE to the label), 2 nsgan
+ * (nn.BCELoss on the raw logits, losses.py:201-202: any logit outside [0,1] is an error in torch; here *loss comes back NaN
+ * and the Python wrapper raises).  mode: 0 = discriminator (0.5*(L(real)+L(fake)), train.py:266-283), 1 = generator
+ * (hinge: -mean * weight; otherwise L(logits, real_label) * weight, train.py:301-308). */
 int p2i_gan_loss(const float* logits_a, const float* logits_b, int n, int loss_type, int mode,
                  float weight, float real_label, float fake_label, float* loss, float* dlogits_a,
                  float* dlogits_b, void* stream);
@@ -236,6 +244,8 @@ int p2i_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, float 
 
 /* small helpers on the same stream */
 int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stream);        /* y += a*x */
+int p2i_add2(float* out, const float* a, const float* b, int64_t n, void* stream);   /* out = a + b (the skip x_4 + res1, p2igan.py:95) */
+int p2i_zero(float* p, int64_t n, void* stream);                                     /* memset 0 on the stream */
 /* out = dy * act'(y) for a saved post-activation tensor y (may alias dy): ReLU / LeakyReLU(0.2) / tanh backward */
 int p2i_act_bwd(const float* dy, const float* y, int act, float* out, int64_t n, void* stream);
 int p2i_bias_grad(const float* dy, const float* y_act, int act, float* db, int B, int C, int64_t inner, void* stream);

@@ -341,6 +341,13 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     out[i] = act_grad(dy[i], y[i], act);
   }
 }
+__global__ void add2_kernel(float* out, const float* __restrict__ a, const float* __restrict__ b, int64_t n4, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+  if (blockIdx.x == 0) for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) out[i] = a[i] + b[i];
+}
 __global__ void axpy_kernel(float* y, const float* __restrict__ x, float a, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += a * x[i];
 }
@@ -481,6 +488,18 @@ extern "C" int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stre
   P2I_REQUIRE(y && x, "null pointer");
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, x, a, n);
   return launch_status();
+}
+extern "C" int p2i_add2(float* out, const float* a, const float* b, int64_t n, void* stream) {
+  P2I_REQUIRE(out && a && b && n >= 0, "null pointer");
+  const bool al = (((uintptr_t)out | (uintptr_t)a | (uintptr_t)b) & 15) == 0;
+  const int64_t n4 = al ? n / 4 : 0;
+  hipLaunchKernelGGL(add2_kernel, dim3(grid_for(n4 + 1)), dim3(256), 0, (hipStream_t)stream, out, a, b, n4, n);
+  return launch_status();
+}
+extern "C" int p2i_zero(float* p, int64_t n, void* stream) {
+  P2I_REQUIRE(p && n >= 0, "null pointer");
+  if (n > 0 && hipMemsetAsync(p, 0, sizeof(float) * (size_t)n, (hipStream_t)stream) != hipSuccess) { set_error("memset failed"); return P2I_EINVAL; }
+  return P2I_OK;
 }
 extern "C" int p2i_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                         int step, void* stream) {

@@ -84,13 +84,24 @@ __global__ void recloss_final_kernel(const float* __restrict__ partial, int np, 
   }
 }
 
-// adversarial losses, single block.  loss_type 0 hinge, 1 lsgan.
+// nn.BCELoss term of the reference's 'nsgan' (losses.py:201-202: BCELoss on the RAW logits): -(y log x + (1-y) log(1-x)) with
+// torch's clamp of the logs at -100; x outside [0,1] is an error in torch (flagged, the loss comes back NaN and the wrapper raises)
+__device__ __forceinline__ float bce_term(float x, float y, bool& bad) {
+  if (!(x >= 0.f && x <= 1.f)) { bad = true; return 0.f; }
+  return -(y * fmaxf(logf(x), -100.f) + (1.f - y) * fmaxf(logf(1.f - x), -100.f));
+}
+__device__ __forceinline__ float bce_grad(float x, float y) {     // d/dx with the same clamps (grad 0 where the log is clamped)
+  const float gl = (logf(x) > -100.f) ? 1.f / x : 0.f, g1 = (logf(1.f - x) > -100.f) ? 1.f / (1.f - x) : 0.f;
+  return -(y * gl - (1.f - y) * g1);
+}
+// adversarial losses, single block.  loss_type 0 hinge, 1 lsgan, 2 nsgan.
 __global__ __launch_bounds__(1024) void gan_loss_kernel(const float* __restrict__ la, const float* __restrict__ lb, int n, int loss_type,
                                                         int mode, float weight, float real_label, float fake_label, float* loss,
                                                         float* da, float* db) {
   __shared__ float red[16];
   const float inv_n = 1.f / (float)n;
   float acc = 0.f;
+  bool bad = false;                                     // nsgan: an input outside [0, 1] (torch's BCELoss raises)
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const float a = la[i];
     if (mode == 0) {                        // discriminator: 0.5*(L(real=a) + L(fake=b))
@@ -99,6 +110,10 @@ __global__ __launch_bounds__(1024) void gan_loss_kernel(const float* __restrict_
         acc += fmaxf(1.f - a, 0.f) + fmaxf(1.f + b, 0.f);
         if (da) da[i] = (1.f - a > 0.f) ? -0.5f * inv_n : 0.f;
         if (db) db[i] = (1.f + b > 0.f) ? 0.5f * inv_n : 0.f;
+      } else if (loss_type == 2) {
+        acc += bce_term(a, real_label, bad) + bce_term(b, fake_label, bad);
+        if (da) da[i] = 0.5f * inv_n * bce_grad(a, real_label);
+        if (db) db[i] = 0.5f * inv_n * bce_grad(b, fake_label);
       } else {
         acc += (a - real_label) * (a - real_label) + (b - fake_label) * (b - fake_label);
         if (da) da[i] = (a - real_label) * inv_n;
@@ -108,6 +123,9 @@ __global__ __launch_bounds__(1024) void gan_loss_kernel(const float* __restrict_
       if (loss_type == 0) {
         acc += -a;
         if (da) da[i] = -weight * inv_n;
+      } else if (loss_type == 2) {
+        acc += bce_term(a, real_label, bad);
+        if (da) da[i] = weight * inv_n * bce_grad(a, real_label);
       } else {
         acc += (a - real_label) * (a - real_label);
         if (da) da[i] = 2.f * (a - real_label) * inv_n * weight;
@@ -115,7 +133,8 @@ __global__ __launch_bounds__(1024) void gan_loss_kernel(const float* __restrict_
     }
   }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) *loss = (mode == 0) ? 0.5f * acc * inv_n : weight * acc * inv_n;
+  const float nbad = block_sum(bad ? 1.f : 0.f, red);
+  if (threadIdx.x == 0) *loss = nbad > 0.f ? NAN : ((mode == 0) ? 0.5f * acc * inv_n : weight * acc * inv_n);
 }
 
 }  // namespace p2i
@@ -144,7 +163,7 @@ extern "C" int p2i_recloss(const float* pred, const float* target, float k1_alph
 extern "C" int p2i_gan_loss(const float* logits_a, const float* logits_b, int n, int loss_type, int mode, float weight,
                             float real_label, float fake_label, float* loss, float* dlogits_a, float* dlogits_b, void* stream) {
   P2I_REQUIRE(logits_a && loss && n > 0, "null pointer");
-  P2I_REQUIRE(loss_type == 0 || loss_type == 1, "loss_type: 0 hinge, 1 lsgan");
+  P2I_REQUIRE(loss_type >= 0 && loss_type <= 2, "loss_type: 0 hinge, 1 lsgan, 2 nsgan");
   P2I_REQUIRE(mode == 1 || logits_b, "discriminator mode needs both logit tensors");
   hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits_a, logits_b, n, loss_type, mode, weight,
                      real_label, fake_label, loss, dlogits_a, dlogits_b);

@@ -523,6 +523,7 @@ struct PackBatch {
   const float* v[PACK_MAX_LAYERS];
   float* dot[PACK_MAX_LAYERS];
   int O[PACK_MAX_LAYERS], I[PACK_MAX_LAYERS], NT[PACK_MAX_LAYERS];
+  int accumulate;                      // unpack: dw += instead of dw =
 };
 __global__ void pack_batched_kernel(const PackBatch b) {
   const int L = blockIdx.z, O = b.O[L], I = b.I[L], NT = b.NT[L];
@@ -556,7 +557,7 @@ __global__ void unpack_batched_kernel(const PackBatch b) {
       const float sg = *b.div[L];
       g = g / sg - (*b.dot[L] / (sg * sg)) * b.u[L][o] * b.v[L][i * NT + tap];
     }
-    b.f[L][idx] = g;
+    if (b.accumulate) b.f[L][idx] += g; else b.f[L][idx] = g;
   }
 }
 }  // namespace p2i
@@ -577,11 +578,13 @@ extern "C" int p2i_weight_pack_batched(const float* const* w, const int* O, cons
   return launch_status();
 }
 
-extern "C" int p2i_weight_unpack_grad_batched(const float* const* dwp_f, const int* O, const int* I, const int* ntaps,
-                                              const float* const* w_orig, const float* const* sigma, const float* const* u,
-                                              const float* const* v, float* dots, float* const* dw, int n, void* stream) {
+extern "C" int p2i_weight_unpack_grad_batched_acc(const float* const* dwp_f, const int* O, const int* I, const int* ntaps,
+                                                  const float* const* w_orig, const float* const* sigma, const float* const* u,
+                                                  const float* const* v, float* dots, float* const* dw, int n, int accumulate,
+                                                  void* stream) {
   P2I_REQUIRE(dwp_f && O && I && ntaps && dw && dots && n >= 1 && n <= PACK_MAX_LAYERS, "1..%d layers", PACK_MAX_LAYERS);
   PackBatch b{};
+  b.accumulate = accumulate;
   int maxn = 0;
   bool any_sigma = false;
   for (int i = 0; i < n; ++i) {
@@ -602,4 +605,10 @@ extern "C" int p2i_weight_unpack_grad_batched(const float* const* dwp_f, const i
   }
   hipLaunchKernelGGL(unpack_batched_kernel, dim3(blocks > 512 ? 512 : blocks, 1, n), dim3(256), 0, s, b);
   return launch_status();
+}
+
+extern "C" int p2i_weight_unpack_grad_batched(const float* const* dwp_f, const int* O, const int* I, const int* ntaps,
+                                              const float* const* w_orig, const float* const* sigma, const float* const* u,
+                                              const float* const* v, float* dots, float* const* dw, int n, void* stream) {
+  return p2i_weight_unpack_grad_batched_acc(dwp_f, O, I, ntaps, w_orig, sigma, u, v, dots, dw, n, 0, stream);
 }

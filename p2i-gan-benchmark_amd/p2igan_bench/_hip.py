@@ -43,6 +43,7 @@ SIGNATURES = {
     "p2i_weight_pack": [_P, _I, _I, _I, _P, _P, _P, _P],
     "p2i_weight_pack_batched": [_P, _P, _P, _P, _P, _P, _P, _I, _P],
     "p2i_weight_unpack_grad_batched": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "p2i_weight_unpack_grad_batched_acc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "p2i_weight_unpack_grad": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "p2i_spectral_norm": [_P, _I, _I, _P, _P, _I, _P, _P, _P],
     "p2i_spectral_norm_batched": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
@@ -64,6 +65,8 @@ SIGNATURES = {
     "p2i_metrics_fss": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, _P, _P, _P],
     "p2i_assemble_batch": [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _P],
     "p2i_axpy": [_P, _P, _F, _L, _P],
+    "p2i_add2": [_P, _P, _P, _L, _P],
+    "p2i_zero": [_P, _L, _P],
     "p2i_act_bwd": [_P, _P, _I, _P, _L, _P],
     "p2i_bias_grad": [_P, _P, _I, _P, _I, _I, _L, _P],
 }

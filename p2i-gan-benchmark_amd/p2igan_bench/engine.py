@@ -13,6 +13,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import ops
+from .models import p2igan as net_fns
 from .modules.losses import ReconstructionLoss, discriminator_loss, generator_adv_loss
 from .parallel import FlatParams, allreduce_mean_, broadcast_module_state
 
@@ -71,9 +72,12 @@ class TrainEngine:
         betas = (opt_cfg.get("beta1", 0.0), opt_cfg.get("beta2", 0.99))
         self.gp = FlatParams(self.G)
         self.opt_g = FusedAdam(self.gp, opt_cfg["lr"], betas)
-        # this engine zeroes the flat gradient buffer before every backward and runs G once per backward: the generator's
-        # backward may write weight gradients straight into the .grad views (models/p2igan.py, eblock_bwd)
-        self.G._grads_inplace = True
+        # direct mode: the step calls the networks' plain forward / backward functions (models/p2igan.py) itself and has
+        # every gradient written straight into the flat buffers -- no autograd graph, no AccumulateGrad / add / fill / copy
+        # kernels from ATen on the step.  P2I_ENGINE_AUTOGRAD=1 keeps the autograd-driven step (same kernels underneath).
+        import os
+        self.direct = os.environ.get("P2I_ENGINE_AUTOGRAD", "0") != "1" and isinstance(self.G, net_fns.P2IGenerator) and (
+            discriminator is None or isinstance(discriminator, net_fns.P2IDiscriminator))
         self.dp = self.opt_d = None
         if self.use_gan:
             self.dp = FlatParams(self.D)
@@ -143,7 +147,54 @@ class TrainEngine:
 
     phase_marks = None      # set to [] to collect 4 events per step: start, after G fwd + rec loss, after the D step, end
 
+    def _step_direct(self, frames, masked, masks) -> Dict[str, torch.Tensor]:
+        """train.py:240-326 with explicit forward / backward calls (see __init__).  Gradient bookkeeping:
+        G: every parameter receives exactly one gradient per step, written (or, for the few atomically accumulated ones, added)
+        into its zeroed view of gp.grad.  D: loss_d.backward() sums the gradients of two forward passes (fake, real) whose
+        spectral-norm sigma / u / v differ (one power iteration per forward): the second pass accumulates."""
+        G, D = self.G, self.D
+        self._mark()
+        G.train()
+        with torch.no_grad():
+            preds, S = net_fns.generator_forward(G, masked, masks, need_grad=True)
+            out3, dpred = ops.recloss(preds.contiguous(), frames.contiguous().float(), self.rec_loss.k1_alpha)
+            out = {"rec": out3[2], "pool": out3[0], "reg": out3[1]}
+            self._mark()
+            dgen = dpred
+            loss_g = out3[2:3]
+            if self.use_gan:
+                D.train()
+                lf, cf = net_fns.discriminator_forward(D, preds, need_x=False, need_p=True, pool=True)
+                lr_, cr = net_fns.discriminator_forward(D, frames, need_x=False, need_p=True, pool=True)
+                loss_d, dlr, dlf = ops.gan_loss_d(lr_, lf, self.gan_type, self.real_label, self.fake_label)
+                self.dp.zero_grad()
+                net_fns.discriminator_backward(D, cf, dlf, need_x=False, inplace=True, accumulate=False)
+                net_fns.discriminator_backward(D, cr, dlr, need_x=False, inplace=True, accumulate=True)
+                del cf, cr
+                if self.distributed:
+                    _allreduce_mean(self.dp.grad, self.world)
+                self.opt_d.step()
+                self._mark()
+                lg, cg = net_fns.discriminator_forward(D, preds, need_x=True, need_p=False, pool=True)
+                adv, dlg = ops.gan_loss_g(lg, self.adv_weight, self.gan_type, self.real_label)
+                # d(rec)/d(preds) rides into the discriminator's first-layer dgrad as its additive term
+                dgen, _, _, _ = net_fns.discriminator_backward(D, cg, dlg, need_x=True, needs=[False] * (2 * 10 + 1), dx_add=dpred)
+                del cg
+                loss_g = ops.add2(out3[2:3], adv)
+                out.update(loss_d=loss_d.reshape(()), adv=adv.reshape(()), logits_real=lr_, logits_fake=lf)
+            self.gp.zero_grad()
+            net_fns.generator_backward(G, S, dgen, inplace=True)
+            del S
+            if self.distributed:
+                _allreduce_mean(self.gp.grad, self.world)
+            self.opt_g.step()
+            out.update(loss_g=loss_g.reshape(()), preds=preds)
+            self._mark()
+        return out
+
     def _step_impl(self, frames, masked, masks) -> Dict[str, torch.Tensor]:
+        if self.direct:
+            return self._step_direct(frames, masked, masks)
         self._mark()
         self.G.train()
         preds = self.G(masked, masks)

@@ -184,165 +184,194 @@ def _doconv_of(holder):      # BasicConv holder -> DOConv params
     return holder.main[0]
 
 
+def _grad_target(prm, inplace):
+    """The parameter's view of the flat gradient buffer when gradients are written in place (TrainEngine), else None."""
+    return prm.grad if inplace else None
+
+
+def generator_forward(net: "P2IGenerator", masked_frames, masks, need_grad: bool):
+    """P2IGenerator.forward (p2igan.py:72-112) as a plain function: returns (frames (B,T,1,H,W), saved state or None).
+    Sequences the kernels of p2igan_bench.ops; no autograd involved (TrainEngine calls this directly, _GeneratorFn wraps it)."""
+    b, t, c, h, w = masked_frames.shape
+    BASE_CH = net.base
+    if c != 1 or t != net.length:
+        raise RuntimeError(f"generator expects (B,{net.length},1,H,W), got {tuple(masked_frames.shape)}")
+    if h % 8 or w % 8:
+        raise RuntimeError("H and W must be multiples of 8")
+    if need_grad and net.inference:
+        raise RuntimeError("P2IGenerator(inference=True) holds folded DO-Conv kernels and is forward-only")
+
+    def fold(conv, out_ch, in_ch, groups, ksz, identity_rep=0):
+        make = lambda: ops.doconv_fold(*conv.tensors(), out_ch, in_ch, groups, ksz, identity_rep=identity_rep, need_d=need_grad)
+        return make() if need_grad else net._cached(id(conv), conv.tensors(), make)
+
+    x0 = masked_frames.reshape(b, t, h, w).contiguous().float()
+    mk = masks.reshape(b, t, h, w).contiguous().float()
+    att = [l.conv for l in net.input.layers]
+    a = ops.attn_fwd(x0, att[0].weight, att[0].bias, att[1].weight, att[1].bias)
+    idw, sel = ops.idw_fwd(a, mk, tau=0.05, save=need_grad)
+    del a
+    cin = _doconv_of(net.Convsin[0])
+    wp_in = fold(cin, BASE_CH, t, 4, 3, identity_rep=4)
+    spec_in = _spec2d(t, BASE_CH, 3)
+    x_ = ops.conv_fwd(spec_in, idw, wp_in[0])
+    x_2 = ops.pooldup_fwd(x_)
+    x_4 = ops.pooldup_fwd(x_2)
+    x_8 = ops.pooldup_fwd(x_4)
+
+    def eblock(lvl, hcur):
+        ch = BASE_CH << lvl
+        spec = _spec2d(ch, ch, 3)
+        rec = []
+        folded = {}
+        if need_grad:                                # the level's 2*num_res same-shape folds in ONE launch
+            convs = [_doconv_of(m) for rb in net.Decoder[lvl].layers for m in (rb.main[0], rb.main[1])]
+            for cv, wp in zip(convs, ops.doconv_fold_batched([cv.tensors() for cv in convs], ch, ch, need_d=True)):
+                folded[id(cv)] = wp
+        for rb in net.Decoder[lvl].layers:
+            c1, c2 = _doconv_of(rb.main[0]), _doconv_of(rb.main[1])
+            w1 = folded[id(c1)] if need_grad else fold(c1, ch, ch, 1, 3)
+            w2 = folded[id(c2)] if need_grad else fold(c2, ch, ch, 1, 3)
+            y1 = ops.conv_fwd(spec, hcur, w1[0], act=ACT_RELU)
+            hn = ops.conv_fwd(spec, y1, w2[0], residual=hcur)
+            rec.append((hcur, y1, w1[1], w2[1]))
+            hcur = hn
+        return hcur, rec
+
+    def uppos(i, hcur):
+        up = net.UP[i]
+        cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
+        u = ops.upmod_fwd(hcur, up.pos)
+        pack = lambda: ops.weight_pack(up.proj.weight.reshape(cout_, cin_, 1), need_d=need_grad)
+        wp = pack() if need_grad else net._cached(id(up), (up.proj.weight,), pack)
+        r = ops.conv_fwd(_spec2d(cin_, cout_, 1), u, wp[0], bias=up.proj.bias, act=ACT_RELU)
+        return r, (hcur, u, r, wp[1])
+
+    h3, rec3 = eblock(3, x_8)
+    res1, up2 = uppos(2, h3)
+    x4s = ops.add2(x_4, res1)                                   # x_4 + res1, p2igan.py:95 (the only skip)
+    h2, rec2 = eblock(2, x4s)
+    res2, up1 = uppos(1, h2)
+    h1, rec1 = eblock(1, res2)
+    res3, up0 = uppos(0, h1)
+    h0, rec0 = eblock(0, res3)
+    cout = _doconv_of(net.ConvsOut[0])
+    wp_out = fold(cout, t, BASE_CH, 4, 1)
+    spec_out = _spec2d(BASE_CH, t, 1)
+    z = ops.conv_fwd(spec_out, h0, wp_out[0], act=ACT_TANH)
+    if net.debug_taps is not None:
+        net.debug_taps.update(idw=idw, x_=x_, x_8=x_8, dec3=h3, res1=res1, res3=res3)
+    S = None
+    if need_grad:
+        S = dict(x0=x0, idw=idw, sel=sel, wp_in_d=wp_in[1], x_=x_, x_2=x_2, x_4=x_4,
+                 rec=[rec0, rec1, rec2, rec3], up=[up0, up1, up2], h0=h0, z=z, wp_out_d=wp_out[1], shape=(b, t, h, w))
+    return z.view(b, t, c, h, w), S
+
+
+def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False):
+    """Hand-sequenced backward of generator_forward.  inplace=False: returns {id(parameter): gradient}.  inplace=True (TrainEngine:
+    every .grad is a zeroed view of the flat gradient buffer and every parameter is used once): gradients are written straight
+    into the .grad views -- no AccumulateGrad add, no copy -- and an empty dict is returned."""
+    b, t, h, w = S["shape"]
+    BASE_CH = net.base
+    grads = {}
+    if inplace and any(p_.requires_grad and (p_.grad is None or not p_.grad.is_contiguous()) for p_ in net.parameters()):
+        raise RuntimeError("generator_backward(inplace=True) needs contiguous .grad views on every trainable parameter")
+    # in-place mode owns a persistent arena (nothing of it outlives this call); the autograd path hands arena views to
+    # AccumulateGrad, which may keep them, so it gets a fresh one
+    if inplace and (getattr(net, "_arena_buf", None) is None or net._arena_buf.numel() < net._arena_numel() or net._arena_buf.device != dout.device):
+        net._arena_buf = torch.empty(net._arena_numel(), device=dout.device, dtype=torch.float32)
+    arena = ops.ZeroArena(net._arena_numel(), dout.device, buf=net._arena_buf if inplace else None)
+    dz = dout.reshape(b, t, h, w).contiguous().float()
+    # ---- ConvsOut (grouped 1x1, dense-lowered) + tanh
+    spec_out = _spec2d(BASE_CH, t, 1)
+    cout = _doconv_of(net.ConvsOut[0])
+    dz = ops.act_bwd(dz, S["z"], ACT_TANH)                      # * (1 - z^2): prologue-free kernels below
+    dwp, _ = ops.conv_wgrad(spec_out, S["h0"], dz, arena=arena)
+    gw, _ = ops.doconv_fold_bwd(dwp, *cout.tensors(), t, BASE_CH, 4, 1, out=(cout.W.grad, None) if inplace else None)
+    if not inplace:
+        grads[id(cout.W)] = gw
+    dh = ops.conv_dgrad(spec_out, dz, S["wp_out_d"], tuple(S["h0"].shape))
+
+    def eblock_bwd(lvl, dh):
+        ch = BASE_CH << lvl
+        spec = _spec2d(ch, ch, 3)
+        blocks = net.Decoder[lvl].layers
+        pend = []                                    # (packed weight gradient, layer): folded back in two launches per level
+        for rb, (hin, y1, w1d, w2d) in zip(reversed(list(blocks)), reversed(S["rec"][lvl])):
+            c1, c2 = _doconv_of(rb.main[0]), _doconv_of(rb.main[1])
+            dwp2, _ = ops.conv_wgrad(spec, y1, dh, arena=arena)
+            pend.append((dwp2, c2))
+            dy1 = ops.conv_dgrad(spec, dh, w2d, tuple(y1.shape), mask_y=y1, mask_act=ACT_RELU)   # * relu'(y1) fused
+            dwp1, _ = ops.conv_wgrad(spec, hin, dy1, arena=arena)
+            pend.append((dwp1, c1))
+            dh = ops.conv_dgrad(spec, dy1, w1d, tuple(hin.shape), add=dh)                     # + skip path
+        outs = ([cv.W.grad for _, cv in pend], [cv.D.grad for _, cv in pend]) if inplace else None
+        dWs, dDs = ops.doconv_fold_bwd_batched([g_ for g_, _ in pend], [cv.tensors() for _, cv in pend], ch, ch, outs=outs)
+        if not inplace:
+            for (_, cv), dW_, dD_ in zip(pend, dWs, dDs):
+                grads[id(cv.W)], grads[id(cv.D)] = dW_, dD_
+        return dh
+
+    def uppos_bwd(i, dr):
+        up = net.UP[i]
+        hin, u, r, wpd = S["up"][i]
+        cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
+        spec = _spec2d(cin_, cout_, 1)
+        dr = ops.act_bwd(dr, r, ACT_RELU)                       # * relu'(r) once, for wgrad and dgrad
+        dwp, db = ops.conv_wgrad(spec, u, dr, want_bias=True, arena=arena, db_out=_grad_target(up.proj.bias, inplace))
+        gw_ = ops.weight_unpack_grad(dwp, up.proj.weight.reshape(cout_, cin_, 1), out=_grad_target(up.proj.weight, inplace))
+        du = ops.conv_dgrad(spec, dr, wpd, tuple(u.shape))
+        dx, dpos = ops.upmod_bwd(hin, up.pos, du, dpos_out=_grad_target(up.pos, inplace))
+        if not inplace:
+            grads[id(up.proj.weight)] = gw_.reshape(up.proj.weight.shape)
+            grads[id(up.proj.bias)] = db
+            grads[id(up.pos)] = dpos
+        return dx
+
+    dh = eblock_bwd(0, dh)
+    dh = uppos_bwd(0, dh)
+    dh = eblock_bwd(1, dh)
+    dh = uppos_bwd(1, dh)
+    dx4s = eblock_bwd(2, dh)              # grad of x_4 + res1: flows to both terms
+    dh = uppos_bwd(2, dx4s)
+    dx8 = eblock_bwd(3, dh)
+    dx4 = ops.axpy_(ops.pooldup_bwd(S["x_4"], dx8), dx4s)
+    dx2 = ops.pooldup_bwd(S["x_2"], dx4)
+    dx_ = ops.pooldup_bwd(S["x_"], dx2)
+    # ---- Convsin (grouped 3x3 + repeat_interleave skip, dense-lowered with centre identity)
+    spec_in = _spec2d(t, BASE_CH, 3)
+    cin = _doconv_of(net.Convsin[0])
+    dwp, _ = ops.conv_wgrad(spec_in, S["idw"], dx_, arena=arena)
+    gW, gD = ops.doconv_fold_bwd(dwp, *cin.tensors(), BASE_CH, t, 4, 3, out=(cin.W.grad, cin.D.grad) if inplace else None)
+    if not inplace:
+        grads[id(cin.W)], grads[id(cin.D)] = gW, gD
+    didw = ops.conv_dgrad(spec_in, dx_, S["wp_in_d"], tuple(S["idw"].shape))
+    da = ops.idw_bwd(didw, S["sel"])
+    att = [l.conv for l in net.input.layers]
+    prm4 = (att[0].weight, att[0].bias, att[1].weight, att[1].bias)
+    g = ops.attn_bwd(S["x0"], *prm4, da, out=[p_.grad for p_ in prm4] if inplace else None)
+    if not inplace:
+        for prm, gr in zip(prm4, g):
+            grads[id(prm)] = gr.reshape(prm.shape)
+    return grads
+
+
 class _GeneratorFn(torch.autograd.Function):
-    """P2IGenerator.forward (p2igan.py:72-112) and its hand-sequenced backward."""
+    """Autograd face of generator_forward / generator_backward (drop-in users: loss.backward() works as with the reference)."""
 
     @staticmethod
     def forward(ctx, net: P2IGenerator, masked_frames, masks, *params):
-        b, t, c, h, w = masked_frames.shape
-        BASE_CH = net.base
-        if c != 1 or t != net.length:
-            raise RuntimeError(f"generator expects (B,{net.length},1,H,W), got {tuple(masked_frames.shape)}")
-        if h % 8 or w % 8:
-            raise RuntimeError("H and W must be multiples of 8")
         need_grad = net._grad_on and any(ctx.needs_input_grad[3:])
-        if need_grad and net.inference:
-            raise RuntimeError("P2IGenerator(inference=True) holds folded DO-Conv kernels and is forward-only")
-
-        def fold(conv, out_ch, in_ch, groups, ksz, identity_rep=0):
-            make = lambda: ops.doconv_fold(*conv.tensors(), out_ch, in_ch, groups, ksz, identity_rep=identity_rep, need_d=need_grad)
-            return make() if need_grad else net._cached(id(conv), conv.tensors(), make)
-
-        x0 = masked_frames.reshape(b, t, h, w).contiguous().float()
-        mk = masks.reshape(b, t, h, w).contiguous().float()
-        S = []                                   # saved state for backward
-        att = [l.conv for l in net.input.layers]
-        a = ops.attn_fwd(x0, att[0].weight, att[0].bias, att[1].weight, att[1].bias)
-        idw, sel = ops.idw_fwd(a, mk, tau=0.05, save=need_grad)
-        del a
-        cin = _doconv_of(net.Convsin[0])
-        wp_in = fold(cin, BASE_CH, t, 4, 3, identity_rep=4)
-        spec_in = _spec2d(t, BASE_CH, 3)
-        x_ = ops.conv_fwd(spec_in, idw, wp_in[0])
-        x_2 = ops.pooldup_fwd(x_)
-        x_4 = ops.pooldup_fwd(x_2)
-        x_8 = ops.pooldup_fwd(x_4)
-
-        def eblock(lvl, hcur):
-            ch = BASE_CH << lvl
-            spec = _spec2d(ch, ch, 3)
-            rec = []
-            folded = {}
-            if need_grad:                                # the level's 2*num_res same-shape folds in ONE launch
-                convs = [_doconv_of(m) for rb in net.Decoder[lvl].layers for m in (rb.main[0], rb.main[1])]
-                for cv, wp in zip(convs, ops.doconv_fold_batched([cv.tensors() for cv in convs], ch, ch, need_d=True)):
-                    folded[id(cv)] = wp
-            for rb in net.Decoder[lvl].layers:
-                c1, c2 = _doconv_of(rb.main[0]), _doconv_of(rb.main[1])
-                w1 = folded[id(c1)] if need_grad else fold(c1, ch, ch, 1, 3)
-                w2 = folded[id(c2)] if need_grad else fold(c2, ch, ch, 1, 3)
-                y1 = ops.conv_fwd(spec, hcur, w1[0], act=ACT_RELU)
-                hn = ops.conv_fwd(spec, y1, w2[0], residual=hcur)
-                rec.append((hcur, y1, w1[1], w2[1]))
-                hcur = hn
-            return hcur, rec
-
-        def uppos(i, hcur):
-            up = net.UP[i]
-            cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
-            u = ops.upmod_fwd(hcur, up.pos)
-            pack = lambda: ops.weight_pack(up.proj.weight.reshape(cout_, cin_, 1), need_d=need_grad)
-            wp = pack() if need_grad else net._cached(id(up), (up.proj.weight,), pack)
-            r = ops.conv_fwd(_spec2d(cin_, cout_, 1), u, wp[0], bias=up.proj.bias, act=ACT_RELU)
-            return r, (hcur, u, r, wp[1])
-
-        h3, rec3 = eblock(3, x_8)
-        res1, up2 = uppos(2, h3)
-        x4s = ops.axpy_(x_4.clone(), res1)                      # x_4 + res1, p2igan.py:95 (the only skip)
-        h2, rec2 = eblock(2, x4s)
-        res2, up1 = uppos(1, h2)
-        h1, rec1 = eblock(1, res2)
-        res3, up0 = uppos(0, h1)
-        h0, rec0 = eblock(0, res3)
-        cout = _doconv_of(net.ConvsOut[0])
-        wp_out = fold(cout, t, BASE_CH, 4, 1)
-        spec_out = _spec2d(BASE_CH, t, 1)
-        z = ops.conv_fwd(spec_out, h0, wp_out[0], act=ACT_TANH)
-        if net.debug_taps is not None:
-            net.debug_taps.update(idw=idw, x_=x_, x_8=x_8, dec3=h3, res1=res1, res3=res3)
+        z, S = generator_forward(net, masked_frames, masks, need_grad)
         if need_grad:
-            ctx.net = net
-            ctx.S = dict(x0=x0, idw=idw, sel=sel, wp_in_d=wp_in[1], x_=x_, x_2=x_2, x_4=x_4,
-                         rec=[rec0, rec1, rec2, rec3], up=[up0, up1, up2], h0=h0, z=z, wp_out_d=wp_out[1],
-                         shape=(b, t, h, w))
-        return z.view(b, t, c, h, w)
+            ctx.net, ctx.S = net, S
+        return z
 
     @staticmethod
     def backward(ctx, dout):
         net, S = ctx.net, ctx.S
-        b, t, h, w = S["shape"]
-        BASE_CH = net.base
-        grads = {}
-        arena = ops.ZeroArena(net._arena_numel(), dout.device)
-        dz = dout.reshape(b, t, h, w).contiguous().float()
-        # ---- ConvsOut (grouped 1x1, dense-lowered) + tanh
-        spec_out = _spec2d(BASE_CH, t, 1)
-        cout = _doconv_of(net.ConvsOut[0])
-        dz = ops.act_bwd(dz, S["z"], ACT_TANH)                      # * (1 - z^2): prologue-free kernels below
-        dwp, _ = ops.conv_wgrad(spec_out, S["h0"], dz, arena=arena)
-        grads[id(cout.W)], _ = ops.doconv_fold_bwd(dwp, *cout.tensors(), t, BASE_CH, 4, 1)
-        dh = ops.conv_dgrad(spec_out, dz, S["wp_out_d"], tuple(S["h0"].shape))
-
-        def eblock_bwd(lvl, dh):
-            ch = BASE_CH << lvl
-            spec = _spec2d(ch, ch, 3)
-            blocks = net.Decoder[lvl].layers
-            pend = []                                    # (packed weight gradient, layer): folded back in two launches per level
-            for rb, (hin, y1, w1d, w2d) in zip(reversed(list(blocks)), reversed(S["rec"][lvl])):
-                c1, c2 = _doconv_of(rb.main[0]), _doconv_of(rb.main[1])
-                dwp2, _ = ops.conv_wgrad(spec, y1, dh, arena=arena)
-                pend.append((dwp2, c2))
-                dy1 = ops.conv_dgrad(spec, dh, w2d, tuple(y1.shape), mask_y=y1, mask_act=ACT_RELU)   # * relu'(y1) fused
-                dwp1, _ = ops.conv_wgrad(spec, hin, dy1, arena=arena)
-                pend.append((dwp1, c1))
-                dh = ops.conv_dgrad(spec, dy1, w1d, tuple(hin.shape), add=dh)                     # + skip path
-            # TrainEngine mode: the results go straight into the flat gradient buffer (each .grad is a view of it, zeroed
-            # before every backward, each parameter used once) and None is returned for these inputs -> no AccumulateGrad
-            # add kernel per tensor.  Anyone else gets ordinary returned gradients.
-            inplace = getattr(net, "_grads_inplace", False) and all(
-                cv.W.grad is not None and cv.D.grad is not None and cv.W.grad.is_contiguous() and cv.D.grad.is_contiguous() for _, cv in pend)
-            outs = ([cv.W.grad for _, cv in pend], [cv.D.grad for _, cv in pend]) if inplace else None
-            dWs, dDs = ops.doconv_fold_bwd_batched([g_ for g_, _ in pend], [cv.tensors() for _, cv in pend], ch, ch, outs=outs)
-            if not inplace:
-                for (_, cv), dW_, dD_ in zip(pend, dWs, dDs):
-                    grads[id(cv.W)], grads[id(cv.D)] = dW_, dD_
-            return dh
-
-        def uppos_bwd(i, dr):
-            up = net.UP[i]
-            hin, u, r, wpd = S["up"][i]
-            cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
-            spec = _spec2d(cin_, cout_, 1)
-            dr = ops.act_bwd(dr, r, ACT_RELU)                       # * relu'(r) once, for wgrad and dgrad
-            dwp, db = ops.conv_wgrad(spec, u, dr, want_bias=True, arena=arena)
-            grads[id(up.proj.weight)] = ops.weight_unpack_grad(dwp, up.proj.weight.reshape(cout_, cin_, 1)).reshape(up.proj.weight.shape)
-            grads[id(up.proj.bias)] = db
-            du = ops.conv_dgrad(spec, dr, wpd, tuple(u.shape))
-            dx, dpos = ops.upmod_bwd(hin, up.pos, du)
-            grads[id(up.pos)] = dpos
-            return dx
-
-        dh = eblock_bwd(0, dh)
-        dh = uppos_bwd(0, dh)
-        dh = eblock_bwd(1, dh)
-        dh = uppos_bwd(1, dh)
-        dx4s = eblock_bwd(2, dh)              # grad of x_4 + res1: flows to both terms
-        dh = uppos_bwd(2, dx4s)
-        dx8 = eblock_bwd(3, dh)
-        dx4 = ops.axpy_(ops.pooldup_bwd(S["x_4"], dx8), dx4s)
-        dx2 = ops.pooldup_bwd(S["x_2"], dx4)
-        dx_ = ops.pooldup_bwd(S["x_"], dx2)
-        # ---- Convsin (grouped 3x3 + repeat_interleave skip, dense-lowered with centre identity)
-        spec_in = _spec2d(t, BASE_CH, 3)
-        cin = _doconv_of(net.Convsin[0])
-        dwp, _ = ops.conv_wgrad(spec_in, S["idw"], dx_, arena=arena)
-        grads[id(cin.W)], grads[id(cin.D)] = ops.doconv_fold_bwd(dwp, *cin.tensors(), BASE_CH, t, 4, 3)
-        didw = ops.conv_dgrad(spec_in, dx_, S["wp_in_d"], tuple(S["idw"].shape))
-        da = ops.idw_bwd(didw, S["sel"])
-        att = [l.conv for l in net.input.layers]
-        g = ops.attn_bwd(S["x0"], att[0].weight, att[0].bias, att[1].weight, att[1].bias, da)
-        for prm, gr in zip((att[0].weight, att[0].bias, att[1].weight, att[1].bias), g):
-            grads[id(prm)] = gr.reshape(prm.shape)
+        grads = generator_backward(net, S, dout, inplace=False)
         out = []
         for (name, prm), need in zip(net.named_parameters(), ctx.needs_input_grad[3:]):
             out.append(grads.get(id(prm)) if need else None)
@@ -403,6 +432,7 @@ class P2IDiscriminator(nn.Module):
         self.alpha2d = nn.Parameter(torch.tensor(0.0))
         self.alpha3d = nn.Parameter(torch.tensor(0.0))      # declared but unused by forward (p2igan.py:145,170)
         self.debug_taps = None
+        self._pack_pool, self._pack_turn = {}, 0            # reusable packed-weight buffers (discriminator_forward)
         if init_weights:
             self.init_weights()
         self.specs2d, cin = [], in_channels
@@ -437,99 +467,140 @@ class P2IDiscriminator(nn.Module):
         return _DiscriminatorFn.apply(self, x, *params)
 
 
+def discriminator_forward(net: "P2IDiscriminator", x, need_x: bool, need_p: bool, pool: bool = False):
+    """P2IDiscriminator.forward (p2igan.py:157-173) incl. the spectral-norm power iteration, as a plain function: returns
+    (logits (B, H/4*W/4), saved context or None).  pool=True (TrainEngine only: at most three forwards pending): the packed
+    weights live in a round-robin of four reusable buffers instead of a fresh zero-filled one per call."""
+    b, t, c, h, w = x.shape
+    if c * t != net.in_channels:
+        raise RuntimeError(f"discriminator expects {net.in_channels} frames, got {t}x{c}")
+    xin = x.contiguous().float()
+    l2, l3 = net.layers()
+    training = net.training
+
+    # power iteration of all ten layers in 4 launches (parameters only; u, v are updated in place as torch does)
+    sn = ops.spectral_norm_batched([m.weight_orig for m in l2 + l3], [m.weight_u for m in l2 + l3],
+                                   [m.weight_v for m in l2 + l3], training, snapshot=need_p)
+    sig_all, usn, vsn = sn if need_p else (sn, None, None)
+    sig_of = {id(m): sg for m, sg in zip(l2 + l3, sig_all)}
+    uv_of = {id(m): (usn[i], vsn[i]) for i, m in enumerate(l2 + l3)} if need_p else {}
+    # weight / sigma, packed for the conv engine: all ten layers in ONE launch.  The packed buffers come from a small pool
+    # of zero-initialised buffers (the pack kernel rewrites exactly the non-padding entries); three forwards can be pending
+    # in one train step (fake, real, fake-for-G), hence the round-robin of four.
+    wflats = [m.weight_orig.reshape(m.weight_orig.shape[0], m.weight_orig.shape[1], -1) for m in l2 + l3]
+    need_d = need_x or need_p
+    pbuf = None
+    if pool:
+        bufs = net._pack_pool.setdefault((need_d, str(xin.device)), [None] * 4)
+        net._pack_turn = (net._pack_turn + 1) % 4
+        if bufs[net._pack_turn] is None:
+            tot = sum(wf.shape[2] * wf.shape[1] * ops.pad32(wf.shape[0]) + (wf.shape[2] * wf.shape[0] * ops.pad32(wf.shape[1]) if need_d else 0)
+                      for wf in wflats)
+            bufs[net._pack_turn] = ops.zero_(torch.empty(tot, device=xin.device, dtype=torch.float32))
+        pbuf = bufs[net._pack_turn]
+    packed = ops.weight_pack_batched(wflats, sig_all, need_d=need_d, buf=pbuf)
+    pack_of = {id(m): pk for m, pk in zip(l2 + l3, packed)}
+
+    def branch(layers, specs, inp):
+        recs, cur = [], inp
+        for n, (m, spec) in enumerate(zip(layers, specs)):
+            sigma = sig_of[id(m)]
+            wp_f, wp_d = pack_of[id(m)]
+            act = ACT_LEAKY if n < 4 else ACT_NONE
+            y = ops.conv_fwd(spec, cur, wp_f, bias=m.bias, act=act)
+            recs.append(dict(x=cur, y=y, wp_d=wp_d, sigma=sigma, act=act,
+                             u=uv_of[id(m)][0] if need_p else None, v=uv_of[id(m)][1] if need_p else None))
+            cur = y
+        return cur, recs
+
+    o2, r2 = branch(l2, net.specs2d, xin.view(b, t * c, h, w))
+    o3, r3 = branch(l3, net.specs3d, xin.view(b, c, t, h, w))      # permute(0,2,1,3,4) with c == 1 is a view
+    fused = ops.dtail_fwd(o2, o3, net.alpha2d.reshape(1))
+    if net.debug_taps is not None:
+        net.debug_taps.update(out2d=o2, out3d=o3)
+    ctx = dict(r2=r2, r3=r3, xshape=(b, t, c, h, w)) if (need_x or need_p) else None
+    return fused, ctx
+
+
+def discriminator_backward(net: "P2IDiscriminator", ctx, dfused, need_x: bool, needs=None, inplace: bool = False,
+                           accumulate: bool = False, dx_add=None):
+    """Backward of discriminator_forward.  needs: per-parameter flags in the order [w0, b0, w1, b1, ..., alpha2d] (None: all /
+    none according to ctx).  Returns (dx or None, gw {layer: dW}, gb {layer: db}, dalpha).  inplace=True (TrainEngine): the
+    gradients are ADDED into the parameters' .grad views (zeroed by the caller before the first backward of a D step;
+    accumulate=True on the second one, whose weight gradients pass through a different sigma / u / v).  dx_add: a tensor shaped
+    like the input that is added to dx (the reconstruction loss's gradient w.r.t. the frames: fused into the first layer's dgrad)."""
+    r2, r3 = ctx["r2"], ctx["r3"]
+    b, t, c, h, w = ctx["xshape"]
+    l2, l3 = net.layers()
+    nl = len(l2) + len(l3)
+    if needs is None:
+        needs = [r2[0]["u"] is not None] * (2 * nl + 1)
+    need_alpha = needs[2 * nl]
+    o2, o3 = r2[-1]["y"], r3[-1]["y"]
+    da_t = net.alpha2d.grad.reshape(1) if (inplace and need_alpha) else None
+    d2, d3, da = ops.dtail_bwd(o2, tuple(o3.shape), net.alpha2d.reshape(1), dfused.contiguous().float(), need_alpha=need_alpha, da_out=da_t)
+    gw, gb = {}, {}
+    pend = []                 # (layer index, packed weight gradient, flat weight, record, shape, module): unpacked together at the end
+    arena = None
+    if any(needs[:2 * nl]):
+        tot = sum(sp.ntaps * sp.cin * ops.pad32(sp.cout) + sp.cout + 8 for sp in net.specs2d + net.specs3d)
+        if inplace and (getattr(net, "_arena_buf", None) is None or net._arena_buf.numel() < tot or net._arena_buf.device != dfused.device):
+            net._arena_buf = torch.empty(tot, device=dfused.device, dtype=torch.float32)
+        arena = ops.ZeroArena(tot, dfused.device, buf=net._arena_buf if inplace else None)
+
+    def branch_bwd(layers, specs, recs, dy, base, first_add=None):
+        # dy arrives already multiplied by act'(y_n): the dgrad of layer n+1 applies it in its epilogue
+        # (mask_y = that layer's input = y_n), so no kernel here needs an activation prologue
+        for n in reversed(range(len(layers))):
+            m, spec, rc = layers[n], specs[n], recs[n]
+            if needs[2 * (base + n)] or needs[2 * (base + n) + 1]:
+                dwp, db = ops.conv_wgrad(spec, rc["x"], dy, want_bias=True, arena=arena, db_out=_grad_target(m.bias, inplace))
+                wo = m.weight_orig
+                pend.append((base + n, dwp, wo.reshape(wo.shape[0], wo.shape[1], -1), rc, wo.shape, m))
+                gb[base + n] = db
+            if n > 0 or need_x:
+                dy = ops.conv_dgrad(spec, dy, rc["wp_d"], tuple(rc["x"].shape), add=first_add if n == 0 else None,
+                                    mask_y=rc["x"] if n > 0 else None, mask_act=ACT_LEAKY)
+            else:
+                dy = None
+        return dy
+
+    add3 = dx_add.reshape(b, c, t, h, w).contiguous() if (dx_add is not None and need_x) else None
+    dx3 = branch_bwd(l3, net.specs3d, r3, d3, len(l2), first_add=add3)
+    dx = branch_bwd(l2, net.specs2d, r2, d2, 0, first_add=dx3.view(b, t * c, h, w) if dx3 is not None else None)
+    if pend:                  # d(weight_orig) through weight / sigma for every layer, in two launches
+        outs = [p_[5].weight_orig.grad for p_ in pend] if inplace else None
+        dws = ops.weight_unpack_grad_batched([p_[1] for p_ in pend], [p_[2] for p_ in pend], [p_[2] for p_ in pend],
+                                             [p_[3]["sigma"] for p_ in pend], [p_[3]["u"] for p_ in pend], [p_[3]["v"] for p_ in pend],
+                                             outs=outs, accumulate=inplace and accumulate)
+        for p_, dw_ in zip(pend, dws):
+            gw[p_[0]] = dw_.reshape(p_[4])
+    return (dx.view(b, t, c, h, w) if need_x else None), gw, gb, da
+
+
 class _DiscriminatorFn(torch.autograd.Function):
-    """P2IDiscriminator.forward (p2igan.py:157-173) incl. spectral-norm power iteration, and backward."""
+    """Autograd face of discriminator_forward / discriminator_backward."""
 
     @staticmethod
     def forward(ctx, net: P2IDiscriminator, x, *params):
-        b, t, c, h, w = x.shape
-        if c * t != net.in_channels:
-            raise RuntimeError(f"discriminator expects {net.in_channels} frames, got {t}x{c}")
-        xin = x.contiguous().float()
-        l2, l3 = net.layers()
         need_x = net._grad_on and ctx.needs_input_grad[1]
         need_p = net._grad_on and any(ctx.needs_input_grad[2:])
-        training = net.training
-
-        # power iteration of all ten layers in 4 launches (parameters only; u, v are updated in place as torch does)
-        sn = ops.spectral_norm_batched([m.weight_orig for m in l2 + l3], [m.weight_u for m in l2 + l3],
-                                       [m.weight_v for m in l2 + l3], training, snapshot=need_p)
-        sig_all, usn, vsn = sn if need_p else (sn, None, None)
-        sig_of = {id(m): sg for m, sg in zip(l2 + l3, sig_all)}
-        uv_of = {id(m): (usn[i], vsn[i]) for i, m in enumerate(l2 + l3)} if need_p else {}
-        # weight / sigma, packed for the conv engine: all ten layers in ONE launch
-        wflats = [m.weight_orig.reshape(m.weight_orig.shape[0], m.weight_orig.shape[1], -1) for m in l2 + l3]
-        packed = ops.weight_pack_batched(wflats, sig_all, need_d=(need_x or need_p))
-        pack_of = {id(m): pk for m, pk in zip(l2 + l3, packed)}
-
-        def branch(layers, specs, inp):
-            recs, cur = [], inp
-            for n, (m, spec) in enumerate(zip(layers, specs)):
-                wo = m.weight_orig
-                sigma = sig_of[id(m)]
-                wp_f, wp_d = pack_of[id(m)]
-                act = ACT_LEAKY if n < 4 else ACT_NONE
-                y = ops.conv_fwd(spec, cur, wp_f, bias=m.bias, act=act)
-                recs.append(dict(x=cur, y=y, wp_d=wp_d, sigma=sigma, act=act,
-                                 u=uv_of[id(m)][0] if need_p else None, v=uv_of[id(m)][1] if need_p else None))
-                cur = y
-            return cur, recs
-
-        o2, r2 = branch(l2, net.specs2d, xin.view(b, t * c, h, w))
-        o3, r3 = branch(l3, net.specs3d, xin.view(b, c, t, h, w))      # permute(0,2,1,3,4) with c == 1 is a view
-        fused = ops.dtail_fwd(o2, o3, net.alpha2d.reshape(1))
-        if net.debug_taps is not None:
-            net.debug_taps.update(out2d=o2, out3d=o3)
+        fused, saved = discriminator_forward(net, x, need_x, need_p)
         if need_x or need_p:
-            ctx.net, ctx.r2, ctx.r3, ctx.xshape = net, r2, r3, (b, t, c, h, w)
+            ctx.net, ctx.saved = net, saved
         return fused
 
     @staticmethod
     def backward(ctx, dfused):
-        net, r2, r3 = ctx.net, ctx.r2, ctx.r3
-        b, t, c, h, w = ctx.xshape
-        l2, l3 = net.layers()
+        net = ctx.net
         need_x = ctx.needs_input_grad[1]
         needs = ctx.needs_input_grad[2:]
-        nl = len(l2) + len(l3)
-        need_alpha = needs[2 * nl]
-        o2, o3 = r2[-1]["y"], r3[-1]["y"]
-        d2, d3, da = ops.dtail_bwd(o2, tuple(o3.shape), net.alpha2d.reshape(1), dfused.contiguous().float(), need_alpha=need_alpha)
-        gw, gb = {}, {}
-        pend = []                 # (layer index, packed weight gradient, flat weight, record, shape): unpacked together at the end
-        arena = None
-        if any(needs[:2 * nl]):
-            tot = sum(sp.ntaps * sp.cin * ops.pad32(sp.cout) + sp.cout + 8 for sp in net.specs2d + net.specs3d)
-            arena = ops.ZeroArena(tot, dfused.device)
-
-        def branch_bwd(layers, specs, recs, dy, base, first_add=None):
-            # dy arrives already multiplied by act'(y_n): the dgrad of layer n+1 applies it in its epilogue
-            # (mask_y = that layer's input = y_n), so no kernel here needs an activation prologue
-            for n in reversed(range(len(layers))):
-                m, spec, rc = layers[n], specs[n], recs[n]
-                if needs[2 * (base + n)] or needs[2 * (base + n) + 1]:
-                    dwp, db = ops.conv_wgrad(spec, rc["x"], dy, want_bias=True, arena=arena)
-                    wo = m.weight_orig
-                    pend.append((base + n, dwp, wo.reshape(wo.shape[0], wo.shape[1], -1), rc, wo.shape))
-                    gb[base + n] = db
-                if n > 0 or need_x:
-                    dy = ops.conv_dgrad(spec, dy, rc["wp_d"], tuple(rc["x"].shape), add=first_add if n == 0 else None,
-                                        mask_y=rc["x"] if n > 0 else None, mask_act=ACT_LEAKY)
-                else:
-                    dy = None
-            return dy
-
-        dx3 = branch_bwd(l3, net.specs3d, r3, d3, len(l2))
-        dx = branch_bwd(l2, net.specs2d, r2, d2, 0, first_add=dx3.view(b, t * c, h, w) if dx3 is not None else None)
-        if pend:                  # d(weight_orig) through weight / sigma for every layer, in two launches
-            dws = ops.weight_unpack_grad_batched([p_[1] for p_ in pend], [p_[2] for p_ in pend], [p_[2] for p_ in pend],
-                                                 [p_[3]["sigma"] for p_ in pend], [p_[3]["u"] for p_ in pend], [p_[3]["v"] for p_ in pend])
-            for p_, dw_ in zip(pend, dws):
-                gw[p_[0]] = dw_.reshape(p_[4])
+        nl = (len(needs) - 1) // 2
+        dx, gw, gb, da = discriminator_backward(net, ctx.saved, dfused, need_x, needs=list(needs))
         out = []
         for i in range(nl):
             out.append(gw.get(i) if needs[2 * i] else None)
             out.append(gb.get(i) if needs[2 * i + 1] else None)
-        out.append(da.reshape(net.alpha2d.shape) if need_alpha else None)
-        ctx.r2 = ctx.r3 = None
-        return (None, dx.view(b, t, c, h, w) if need_x else None, *out)
+        out.append(da.reshape(net.alpha2d.shape) if needs[2 * nl] else None)
+        ctx.saved = None
+        return (None, dx, *out)

@@ -90,17 +90,17 @@ def generator_adv_loss(logits, weight, loss_type="hinge", target_real_label=1.0)
 
 def gan_loss(logits: torch.Tensor, target_is_real: bool, *, loss_type: str = "nsgan", is_disc: bool = False,
              target_real_label: float = 1.0, target_fake_label: float = 0.0) -> torch.Tensor:
-    """Reference-compatible single-term helper (losses.py:232-253).  hinge / lsgan only: the
-    reference's 'nsgan' applies BCELoss to raw logits and raises for any logit outside [0, 1]."""
-    if loss_type not in ("hinge", "lsgan"):
-        raise NotImplementedError(f"gan loss '{loss_type}' is not runnable in the reference either (BCELoss on raw logits)")
+    """Reference-compatible single-term helper (losses.py:232-253): hinge / lsgan / nsgan.  'nsgan' is nn.BCELoss on the RAW
+    logits (losses.py:201-202) and, like torch, raises for any logit outside [0, 1]."""
+    if loss_type not in ("hinge", "lsgan", "nsgan"):
+        raise ValueError(f"Unsupported GAN loss type: {loss_type}")
     if loss_type == "hinge" and is_disc is None:
         raise ValueError("`is_disc` must be set when using hinge loss.")
     if loss_type == "hinge" and not is_disc:
         return generator_adv_loss(logits, 1.0, "hinge", target_real_label)
-    if loss_type == "lsgan":
+    if loss_type in ("lsgan", "nsgan"):
         label = target_real_label if target_is_real else target_fake_label
-        return generator_adv_loss(logits, 1.0, "lsgan", label)       # mean((x-label)^2)
+        return generator_adv_loss(logits, 1.0, loss_type, label)       # mean((x-label)^2) / mean(BCE(x, label))
     # hinge discriminator single term: relu(1 -/+ x).mean() == 2 * D-loss with the other side saturated
     big = torch.full_like(logits, 1e30)
     if target_is_real:

@@ -232,8 +232,13 @@ class ZeroArena:
     """One zero-filled buffer carved into the (atomically accumulated) gradient outputs of a backward pass:
     a single memset instead of one fill kernel per weight tensor."""
 
-    def __init__(self, numel: int, device):
-        self.buf = torch.zeros(numel, device=device, dtype=torch.float32)
+    def __init__(self, numel: int, device, buf: Optional[torch.Tensor] = None):
+        """buf: a caller-owned buffer of >= numel floats to reuse (zeroed here by p2i_zero, no ATen fill kernel)."""
+        if buf is not None and buf.numel() >= numel:
+            self.buf = buf
+            zero_(buf[:numel])
+        else:
+            self.buf = torch.zeros(numel, device=device, dtype=torch.float32)
         self.off = 0
 
     def take(self, shape):
@@ -242,14 +247,15 @@ class ZeroArena:
             n *= d
         n4 = (n + 3) // 4 * 4                       # keep every carve 16-B aligned
         if self.off + n4 > self.buf.numel():
-            return torch.zeros(shape, device=self.buf.device, dtype=torch.float32)
+            return zero_(torch.empty(shape, device=self.buf.device, dtype=torch.float32))
         t = self.buf[self.off:self.off + n].view(shape)
         self.off += n4
         return t
 
 
-def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False, arena: Optional["ZeroArena"] = None):
-    """Packed weight gradient dwp_f [ntaps][cin][pad32(cout)] (+ bias gradient)."""
+def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False, arena: Optional["ZeroArena"] = None, db_out=None):
+    """Packed weight gradient dwp_f [ntaps][cin][pad32(cout)] (+ bias gradient).  db_out: caller-owned (cout,) tensor the bias
+    gradient is ADDED to (e.g. the parameter's view of the flat gradient buffer)."""
     lib = _hip.load()
     b, c, t, h, w = _dims5(x)
     to, ho, wo = spec.out_dims(t, h, w)
@@ -258,12 +264,14 @@ def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False,
         raise RuntimeError(f"conv_wgrad: shape mismatch dy={tuple(dy.shape)} expected {eshape}")
     if y_act is not None and y_act.shape != dy.shape:
         raise RuntimeError("conv_wgrad: y_act shape mismatch")
+    if db_out is not None and (tuple(db_out.shape) != (spec.cout,) or not want_bias):
+        raise RuntimeError("conv_wgrad: db_out must be (cout,) and want_bias set")
     if arena is not None:
         dwp = arena.take(spec.wp_f_shape())
-        db = arena.take((spec.cout,)) if want_bias else None
+        db = db_out if db_out is not None else (arena.take((spec.cout,)) if want_bias else None)
     else:
-        dwp = torch.zeros(spec.wp_f_shape(), device=x.device, dtype=torch.float32)
-        db = torch.zeros(spec.cout, device=x.device, dtype=torch.float32) if want_bias else None
+        dwp = zero_(torch.empty(spec.wp_f_shape(), device=x.device, dtype=torch.float32))
+        db = db_out if db_out is not None else (zero_(torch.empty(spec.cout, device=x.device, dtype=torch.float32)) if want_bias else None)
     _chk(x, dy, y_act, dwp, db)
     d = spec.desc(b, t, h, w)
     e0 = _prof_begin()
@@ -294,12 +302,19 @@ def doconv_fold(W, D, D_diag, out_ch, in_ch, groups, ksz, identity_rep=0, need_d
     return wp_f, wp_d
 
 
-def doconv_fold_bwd(dwp_f, W, D, D_diag, out_ch, in_ch, groups, ksz):
+def doconv_fold_bwd(dwp_f, W, D, D_diag, out_ch, in_ch, groups, ksz, out=None):
+    """out = (dW target, dD target or None): written in place (caller-owned, e.g. views of the flat gradient buffer)."""
     lib = _hip.load()
     if tuple(dwp_f.shape) != (ksz * ksz, in_ch, pad32(out_ch)):
         raise RuntimeError("doconv_fold_bwd: dwp shape mismatch")
-    dW = torch.empty_like(W)
-    dD = torch.empty_like(D) if ksz == 3 else None
+    if out is not None:
+        dW, dD = out
+        if dW.shape != W.shape or (ksz == 3 and (dD is None or dD.shape != D.shape)):
+            raise RuntimeError("doconv_fold_bwd: output target shape mismatch")
+        _chk(dW, dD)
+    else:
+        dW = torch.empty_like(W)
+        dD = torch.empty_like(D) if ksz == 3 else None
     _chk(dwp_f, W, D, D_diag)
     _hip.check(lib.p2i_doconv_fold_bwd(_ptr(dwp_f), _ptr(W), _ptr(D), _ptr(D_diag), out_ch, in_ch, groups, ksz,
                                        _ptr(dW), _ptr(dD), _stream()), "p2i_doconv_fold_bwd")
@@ -370,9 +385,11 @@ def weight_pack(w, sigma=None, need_f=True, need_d=True):
     return wp_f, wp_d
 
 
-def weight_pack_batched(ws, sigmas=None, need_d=True):
+def weight_pack_batched(ws, sigmas=None, need_d=True, buf=None):
     """weight_pack for a list of (O, I, ntaps) weights (different shapes) in ONE launch; one zero-filled buffer holds every
-    packed output (the padded columns must read 0).  Returns [(wp_f, wp_d), ...]."""
+    packed output (the padded columns must read 0).  Returns [(wp_f, wp_d), ...].  buf: a caller-owned buffer that was
+    zero-filled ONCE and is only ever used for this same list of shapes (the pack kernel rewrites exactly the non-padding
+    entries, so the padding stays zero): saves the per-call fill."""
     import ctypes
     lib = _hip.load()
     n = len(ws)
@@ -383,7 +400,11 @@ def weight_pack_batched(ws, sigmas=None, need_d=True):
         _chk(w)
     sizes_f = [nt * i * pad32(o) for o, i, nt in zip(Os, Is, NTs)]
     sizes_d = [nt * o * pad32(i) for o, i, nt in zip(Os, Is, NTs)] if need_d else [0] * n
-    buf = torch.zeros(sum(sizes_f) + sum(sizes_d), device=ws[0].device, dtype=torch.float32)
+    need = sum(sizes_f) + sum(sizes_d)
+    if buf is None:
+        buf = zero_(torch.empty(need, device=ws[0].device, dtype=torch.float32))
+    elif buf.numel() != need:
+        raise RuntimeError("weight_pack_batched: reused buffer has the wrong size")
     outs, off = [], 0
     for k in range(n):
         f = buf[off:off + sizes_f[k]].view(NTs[k], Is[k], pad32(Os[k]))
@@ -400,8 +421,9 @@ def weight_pack_batched(ws, sigmas=None, need_d=True):
     return outs
 
 
-def weight_unpack_grad_batched(dwps, likes, w_origs=None, sigmas=None, us=None, vs=None):
-    """weight_unpack_grad for a list of layers (different shapes) in two launches.  Returns [dw, ...] shaped like `likes`."""
+def weight_unpack_grad_batched(dwps, likes, w_origs=None, sigmas=None, us=None, vs=None, outs=None, accumulate=False):
+    """weight_unpack_grad for a list of layers (different shapes) in two launches.  Returns [dw, ...] shaped like `likes`.
+    outs: caller-owned targets (numel must match); accumulate: dw += instead of dw = (second backward of a D step)."""
     import ctypes
     lib = _hip.load()
     n = len(dwps)
@@ -410,23 +432,35 @@ def weight_unpack_grad_batched(dwps, likes, w_origs=None, sigmas=None, us=None, 
         if tuple(g.shape) != (nt, i, pad32(o)):
             raise RuntimeError("weight_unpack_grad_batched: dwp shape mismatch")
         _chk(g)
-    dws = [torch.empty_like(l) for l in likes]
+    if outs is not None:
+        if len(outs) != n or any(o.numel() != l.numel() for o, l in zip(outs, likes)):
+            raise RuntimeError("weight_unpack_grad_batched: output targets do not match")
+        _chk(*outs)
+        dws = outs
+    else:
+        if accumulate:
+            raise RuntimeError("weight_unpack_grad_batched: accumulate needs caller-owned targets")
+        dws = [torch.empty_like(l) for l in likes]
     dots = torch.empty(n, device=dwps[0].device, dtype=torch.float32)
     arr_i = ctypes.c_int * n
     none = [None] * n
-    _hip.check(lib.p2i_weight_unpack_grad_batched(_ptr_array(dwps), arr_i(*Os), arr_i(*Is), arr_i(*NTs), _ptr_array(w_origs or none),
-                                                  _ptr_array(sigmas or none), _ptr_array(us or none), _ptr_array(vs or none),
-                                                  _ptr(dots), _ptr_array(dws), n, _stream()), "p2i_weight_unpack_grad_batched")
+    _hip.check(lib.p2i_weight_unpack_grad_batched_acc(_ptr_array(dwps), arr_i(*Os), arr_i(*Is), arr_i(*NTs), _ptr_array(w_origs or none),
+                                                      _ptr_array(sigmas or none), _ptr_array(us or none), _ptr_array(vs or none),
+                                                      _ptr(dots), _ptr_array(dws), n, int(accumulate), _stream()),
+               "p2i_weight_unpack_grad_batched_acc")
     return dws
 
 
-def weight_unpack_grad(dwp_f, like, w_orig=None, sigma=None, u=None, v=None):
+def weight_unpack_grad(dwp_f, like, w_orig=None, sigma=None, u=None, v=None, out=None):
     lib = _hip.load()
     O, I = like.shape[0], like.shape[1]
     nt = like[0, 0].numel()
     if tuple(dwp_f.shape) != (nt, I, pad32(O)):
         raise RuntimeError("weight_unpack_grad: dwp shape mismatch")
-    dw = torch.empty_like(like)
+    if out is not None and out.numel() != like.numel():
+        raise RuntimeError("weight_unpack_grad: output target size mismatch")
+    dw = out if out is not None else torch.empty_like(like)
+    _chk(dw)
     scratch = torch.empty(4, device=like.device, dtype=torch.float32) if sigma is not None else None
     _chk(dwp_f, w_orig, sigma, u, v)
     _hip.check(lib.p2i_weight_unpack_grad(_ptr(dwp_f), O, I, nt, _ptr(w_orig), _ptr(sigma), _ptr(u), _ptr(v),
@@ -509,12 +543,19 @@ def attn_fwd(x, w0, b0, w1, b1):
     return out
 
 
-def attn_bwd(x, w0, b0, w1, b1, dout):
+def attn_bwd(x, w0, b0, w1, b1, dout, out=None):
+    """out: four caller-owned, ZEROED targets shaped like (w0, b0, w1, b1) (the kernel adds atomically)."""
     lib = _hip.load()
     B, T, H, W = x.shape
     if dout.shape != x.shape:
         raise RuntimeError("attn_bwd: dout shape mismatch")
-    g = [torch.zeros_like(p) for p in (w0, b0, w1, b1)]
+    if out is not None:
+        if len(out) != 4 or any(o.numel() != p_.numel() for o, p_ in zip(out, (w0, b0, w1, b1))):
+            raise RuntimeError("attn_bwd: output targets do not match")
+        g = list(out)
+        _chk(*g)
+    else:
+        g = [zero_(torch.empty_like(p_)) for p_ in (w0, b0, w1, b1)]
     _chk(x, w0, b0, w1, b1, dout)
     _hip.check(lib.p2i_attn_bwd(_ptr(x), _ptr(w0), _ptr(b0), _ptr(w1), _ptr(b1), _ptr(dout), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]),
                                 _ptr(g[3]), B, T, H * W, _stream()), "p2i_attn_bwd")
@@ -599,13 +640,17 @@ def upmod_fwd(x, pos):
     return u
 
 
-def upmod_bwd(x, pos, du, need_dx=True):
+def upmod_bwd(x, pos, du, need_dx=True, dpos_out=None):
+    """dpos_out: caller-owned ZEROED target shaped like pos (the kernel adds atomically)."""
     lib = _hip.load()
     B, Cc, Sh, Sw = x.shape
     if tuple(du.shape) != (B, Cc, 2 * Sh, 2 * Sw):
         raise RuntimeError("upmod_bwd: du shape mismatch")
     dx = torch.empty_like(x) if need_dx else None
-    dpos = torch.zeros_like(pos)
+    if dpos_out is not None and dpos_out.numel() != pos.numel():
+        raise RuntimeError("upmod_bwd: dpos target size mismatch")
+    dpos = dpos_out if dpos_out is not None else zero_(torch.empty_like(pos))
+    _chk(dpos)
     _chk(x, pos, du)
     _hip.check(lib.p2i_upmod_bwd(_ptr(x), _ptr(pos), _ptr(du), _ptr(dx), _ptr(dpos), B, Cc, Sh, Sw, _stream()), "p2i_upmod_bwd")
     return dx, dpos
@@ -624,13 +669,15 @@ def dtail_fwd(out2d, out3d, alpha2d):
     return fused
 
 
-def dtail_bwd(out2d, out3d_shape, alpha2d, dfused, need_alpha=True):
+def dtail_bwd(out2d, out3d_shape, alpha2d, dfused, need_alpha=True, da_out=None):
+    """da_out: caller-owned (1,) target the alpha2d gradient is ADDED to."""
     lib = _hip.load()
     B, _, H2, W2 = out2d.shape
     _, _, T3, H3, W3 = out3d_shape
     d2 = torch.empty_like(out2d)
     d3 = torch.empty(out3d_shape, device=out2d.device, dtype=torch.float32)
-    da = torch.zeros_like(alpha2d) if need_alpha else None
+    da = (da_out if da_out is not None else zero_(torch.empty_like(alpha2d))) if need_alpha else None
+    _chk(da)
     _chk(out2d, alpha2d, dfused)
     _hip.check(lib.p2i_dtail_bwd(_ptr(out2d), _ptr(alpha2d), _ptr(dfused), _ptr(d2), _ptr(d3), _ptr(da), B, H2, W2, T3, H3, W3,
                                  _stream()), "p2i_dtail_bwd")
@@ -654,31 +701,40 @@ def recloss(pred, target, k1_alpha):
     return out3, dpred
 
 
-_LOSS_TYPES = {"hinge": 0, "lsgan": 1}
+_LOSS_TYPES = {"hinge": 0, "lsgan": 1, "nsgan": 2}
+
+
+def _check_bce(loss, loss_type):
+    """nn.BCELoss (the reference's 'nsgan', losses.py:201-202) raises for inputs outside [0, 1]; the kernel flags that with a NaN
+    loss.  Costs a host sync, on the nsgan path only (the named configs use hinge)."""
+    if loss_type == "nsgan" and bool(torch.isnan(loss).any()):
+        raise RuntimeError("all elements of input should be between 0 and 1")
 
 
 def gan_loss_d(logits_real, logits_fake, loss_type="hinge", real_label=1.0, fake_label=0.0):
     lib = _hip.load()
     if loss_type not in _LOSS_TYPES:
-        raise NotImplementedError(f"gan loss '{loss_type}' (reference nsgan applies BCELoss to raw logits and cannot run)")
+        raise ValueError(f"Unsupported GAN loss type: {loss_type}")
     n = logits_real.numel()
     loss = torch.empty(1, device=logits_real.device, dtype=torch.float32)
     da, db = torch.empty_like(logits_real), torch.empty_like(logits_fake)
     _chk(logits_real, logits_fake)
     _hip.check(lib.p2i_gan_loss(_ptr(logits_real), _ptr(logits_fake), n, _LOSS_TYPES[loss_type], 0, 1.0, real_label, fake_label,
                                 _ptr(loss), _ptr(da), _ptr(db), _stream()), "p2i_gan_loss")
+    _check_bce(loss, loss_type)
     return loss, da, db
 
 
 def gan_loss_g(logits, weight, loss_type="hinge", real_label=1.0):
     lib = _hip.load()
     if loss_type not in _LOSS_TYPES:
-        raise NotImplementedError(f"gan loss '{loss_type}'")
+        raise ValueError(f"Unsupported GAN loss type: {loss_type}")
     loss = torch.empty(1, device=logits.device, dtype=torch.float32)
     da = torch.empty_like(logits)
     _chk(logits)
     _hip.check(lib.p2i_gan_loss(_ptr(logits), None, logits.numel(), _LOSS_TYPES[loss_type], 1, float(weight), real_label, 0.0,
                                 _ptr(loss), _ptr(da), None, _stream()), "p2i_gan_loss")
+    _check_bce(loss, loss_type)
     return loss, da
 
 
@@ -711,6 +767,25 @@ def axpy_(y, x, a=1.0):
     return y
 
 
+def zero_(t):
+    """t[...] = 0 (hipMemsetAsync on torch's current stream)."""
+    lib = _hip.load()
+    _chk(t)
+    _hip.check(lib.p2i_zero(_ptr(t), t.numel(), _stream()), "p2i_zero")
+    return t
+
+
+def add2(a, b):
+    """a + b (new tensor)."""
+    lib = _hip.load()
+    if a.shape != b.shape:
+        raise RuntimeError("add2: shape mismatch")
+    out = torch.empty_like(a)
+    _chk(a, b)
+    _hip.check(lib.p2i_add2(_ptr(out), _ptr(a), _ptr(b), a.numel(), _stream()), "p2i_add2")
+    return out
+
+
 def act_bwd(dy, y, act):
     """dy * act'(y) for the saved post-activation tensor y."""
     lib = _hip.load()
@@ -726,7 +801,7 @@ def bias_grad(dy, y_act=None, act=ACT_NONE):
     lib = _hip.load()
     B, Cc = dy.shape[0], dy.shape[1]
     inner = dy[0, 0].numel()
-    db = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
+    db = zero_(torch.empty(Cc, device=dy.device, dtype=torch.float32))
     _chk(dy, y_act)
     _hip.check(lib.p2i_bias_grad(_ptr(dy), _ptr(y_act), act, _ptr(db), B, Cc, inner, _stream()), "p2i_bias_grad")
     return db

@@ -52,7 +52,11 @@ class FlatParams:
         self.n = n
 
     def zero_grad(self):
-        self.grad.zero_()
+        if self.grad.is_cuda:
+            from . import ops           # p2i_zero (hipMemsetAsync): no ATen fill kernel on the step
+            ops.zero_(self.grad)
+        else:
+            self.grad.zero_()
         off = 0
         for p in self.params:       # autograd accumulates in place; re-attach if something replaced .grad
             k = p.numel()

@@ -9,6 +9,15 @@ TOL = 1e-4          # north_star: 1e-4 relative to max-abs, fp32
 GTOL = 1e-3         # gradients after long reductions / quantities after an Adam step
 
 
+def grad_err(a, b):
+    """rel_err with a floor of 1e-4 on the reference's max-abs: d2d.8.bias's true gradient is EXACTLY 0 at step 0 (the hinge terms
+    of the fake and the real pass cancel: +k/2n - k/2n), and a sum that adds both passes' terms into one fp32 cell in atomic order
+    leaves a ~1e-8 residue instead of the 0 the reference gets by subtracting two equal sums."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-4))
+
+
 def batch_for(g, h, w):
     from p2igan_bench.utils import seeded
     if h == 128:
@@ -46,9 +55,9 @@ def check(g, r, ggrads, dgrads, gstate, dstate, taps=None):
         elif kind == "dgradnorm":
             assert abs(f(dgrads[name].norm()) - f(g[k])) <= GTOL * f(g[k]) + 1e-7, k
         elif kind == "ggrad":
-            assert rel_err(n_(ggrads[name]), g[k]) < GTOL, k
+            assert grad_err(n_(ggrads[name]), g[k]) < GTOL, k
         elif kind == "dgrad":
-            assert rel_err(n_(dgrads[name]), g[k]) < GTOL, k
+            assert grad_err(n_(dgrads[name]), g[k]) < GTOL, k
         elif kind == "g1sum":
             assert abs(f(gstate[name].double().sum()) - f(g[k])) <= 2e-3 * max(1.0, abs(f(g[k]))), k
         elif kind == "d1sum":

@@ -225,8 +225,8 @@ def test_reference_api_gan_loss_matches_oracle(dev):
             (got * 3.0).backward()
             assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref)), (lt, is_real, is_disc)
             assert rel_err(xg.grad.cpu().numpy(), 3.0 * xr.grad.numpy()) < 1e-5, (lt, is_real, is_disc)
-    with pytest.raises(NotImplementedError):
-        gan_loss(x.to(dev), True, loss_type="nsgan", is_disc=True)
+    with pytest.raises(ValueError):
+        gan_loss(x.to(dev), True, loss_type="wgan", is_disc=True)
 
 
 def test_generator_128_matches_reference_golden(dev, golden):
@@ -448,3 +448,44 @@ def test_two_rank_rccl_bench_launch(dev):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
+
+
+def test_autograd_step_matches_direct_step(dev):
+    """TrainEngine's direct step (plain forward / backward functions, gradients written in place) and the autograd-driven step
+    (the drop-in modules + loss.backward(), what a user of the reference API runs) execute the same kernels: one step from the
+    same state must agree to summation-order noise."""
+    from p2igan_bench.engine import TrainEngine
+    frames, masked, masks = [t.to(dev) for t in _batch32()]
+    res = []
+    for direct in (True, False):
+        cfg, G, D = _build(dev)
+        eng = TrainEngine(G, D, cfg)
+        assert eng.direct
+        eng.direct = direct
+        r = eng.train_step(frames, masked, masks)
+        res.append(({k: float(r[k]) for k in ("loss_g", "loss_d", "rec", "adv", "pool", "reg")}, r["preds"].clone(),
+                    eng.gp.grad.clone(), eng.dp.grad.clone()))
+    (la, pa, ga, da), (lb, pb, gb, db) = res
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-5 * abs(la[k]) + 1e-9, (k, la[k], lb[k])
+    assert torch.equal(pa, pb)
+    assert rel_err(gb.cpu().numpy(), ga.cpu().numpy()) < 1e-5
+    assert rel_err(db.cpu().numpy(), da.cpu().numpy()) < 1e-5
+
+
+def test_nsgan_matches_oracle_and_rejects_out_of_range(dev):
+    """'nsgan' = nn.BCELoss on the raw logits (losses.py:201-202): runs only for logits in [0, 1] (torch raises otherwise)."""
+    from oracle import p2i_oracle as orc
+    from p2igan_bench.modules import gan_loss
+    x = torch.rand(2, 1024, generator=torch.Generator().manual_seed(9)) * 0.98 + 0.01
+    for is_real, is_disc in ((True, True), (False, True), (True, False)):
+        xr = x.clone().requires_grad_(True)
+        ref = orc.gan_loss(xr, is_real, "nsgan", is_disc, 0.9, 0.1)
+        ref.backward()
+        xg = x.clone().to(dev).requires_grad_(True)
+        got = gan_loss(xg, is_real, loss_type="nsgan", is_disc=is_disc, target_real_label=0.9, target_fake_label=0.1)
+        got.backward()
+        assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref)), (is_real, is_disc)
+        assert rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1e-5, (is_real, is_disc)
+    with pytest.raises(RuntimeError):
+        gan_loss((x + 0.5).to(dev), True, loss_type="nsgan", is_disc=True)
