@@ -339,9 +339,13 @@ static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, h
   const long long nb = (long long)best_grid.x * best_grid.y * best_grid.z;
   const int acc_regs = (c.MB / 32) * (c.NPIX / 32) / 4 * 16;
   const size_t red_bytes = (size_t)4 * acc_regs * 64 * 4;
-  const int KG = ((nb <= 320 || (c.CK == 16 && max_taps == 9)) && c.CK >= 8 && c.MB <= 64 && red_bytes <= best_lds) ? 2 : 1;
+  // 27-tap (3-D) layers stage 27 * CK weight rows per chunk, so CK stays 4 and one workgroup fills a CU's LDS: give it 8 waves
+  // too (two per SIMD: one wave's DMA issue / LDS waits hide under the other's MFMAs), one channel pair per wave group
+  static const int kg27 = getenv("P2I_CONV_KG27") ? atoi(getenv("P2I_CONV_KG27")) : 1;
+  const bool kg_27 = kg27 && max_taps == 27 && c.CK == 4 && ncls == 1;
+  const int KG = ((nb <= 320 || (c.CK == 16 && max_taps == 9) || kg_27) && (c.CK >= 8 || kg_27) && c.MB <= 64 && red_bytes <= best_lds) ? 2 : 1;
   g_last_plan[0] = c.MB; g_last_plan[1] = c.NPIX; g_last_plan[2] = c.WM; g_last_plan[3] = c.CK;
-  g_last_plan[4] = ncls > 1 ? 0 : ((max_taps == 9 && (c.CK <= 8 || KG == 2)) ? 9 : (max_taps == 1 ? 1 : ((max_taps == 27 && c.CK <= 4 && KG == 1) ? 27 : 0)));
+  g_last_plan[4] = ncls > 1 ? 0 : ((max_taps == 9 && (c.CK <= 8 || KG == 2)) ? 9 : (max_taps == 1 ? 1 : ((max_taps == 27 && (c.CK == 4 || (c.CK < 4 && KG == 1))) ? 27 : 0)));
   g_last_plan[5] = KG;
   return dispatch_patch_dma(c, KG, bg, best_grid, best_lds, s);
 }

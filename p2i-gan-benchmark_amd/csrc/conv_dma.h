@@ -341,7 +341,7 @@ static inline int launch_patch_dma(const PatchGeom& g, dim3 grid, size_t lds, hi
     if (g.ntaps == 9) return launch_patch_dma_nt<MB, NPIX, WM, CK, 9, KG>(g, grid, lds, s);
   }
   if (g.ntaps == 1) return launch_patch_dma_nt<MB, NPIX, WM, CK, 1, KG>(g, grid, lds, s);
-  if constexpr (CK <= 4 && KG == 1) {
+  if constexpr (CK == 4 || (CK < 4 && KG == 1)) {
     if (g.ntaps == 27) return launch_patch_dma_nt<MB, NPIX, WM, CK, 27, KG>(g, grid, lds, s);
   }
   return launch_patch_dma_nt<MB, NPIX, WM, CK, 0, KG>(g, grid, lds, s);

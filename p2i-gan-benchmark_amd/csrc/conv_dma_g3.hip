@@ -7,6 +7,9 @@ int dispatch_patch_dma_g3(const TileCfg& c, int KG, const PatchGeom& g, dim3 gri
   P2I_DMA_CASE(64, 256, 1, 4, 1)
   P2I_DMA_CASE(64, 128, 2, 4, 1)
   P2I_DMA_CASE(32, 128, 1, 4, 1)
+  P2I_DMA_CASE(64, 256, 1, 4, 2)
+  P2I_DMA_CASE(64, 128, 2, 4, 2)
+  P2I_DMA_CASE(32, 128, 1, 4, 2)
   P2I_DMA_CASE(64, 128, 2, 2, 1)
   P2I_DMA_CASE(32, 128, 1, 2, 1)
   return -1;

@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g) {
 // The three dx taps of a kernel row then take registers (k-1, k), i.e. the SAME loaded window, with k = -1 handed over from the
 // previous unit: 6 ds_read_b64 (2-way conflicts) + 1 for dy per 18 MFMAs instead of 18 ds_read_b32 (4-way) + 1 ds_read_b128, every
 // address a per-tile base register + an immediate, no address arithmetic in the loop.
-template <int NPIX, int NTAP, bool Y4, int CB, int LJU = -1>
+// SX = 2 (stride 2 in h and w, pad 1): the x column of pixel p, tap c sits at image index 2p + 3 + c, so an 8-B read at 2p + 2 holds
+// (-, c0) and the next one (c1, c2); the k slots are again the pixel pairs (p, p+2), (p+1, p+3): lanes 32-63 read 8 columns to
+// the right.  12 ds_read_b64 + 1 for dy per 18 MFMAs, no operand is shared between units.
+template <int NPIX, int NTAP, bool Y4, int CB, int LJU = -1, int SX = 1>
 __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int PP = Y4 ? NPIX + 4 : NPIX + 1;
@@ -315,8 +318,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
   // scalar base (soffset, >= 0) and the border tests.  (The generic `issue` above redoes ~30 VALU ops of index arithmetic per DMA
   // instruction, in both waves of every SIMD at once, right after the barrier: the matrix pipe idles behind it.)
   constexpr int NXI = 2, NYI = (64 * PP / 4 + 511) / 512;
-  int xl_off[NXI], xl_col[NXI], yl_off[NYI], yl_jb[NYI], yl_jh[NYI], yl_jw[NYI];
-  bool xl_ok[NXI], yl_ok[NYI];
+  int xl_off[NXI], xl_col[NXI], yl_off[NYI], yl_pos[NYI];       // offsets < 0: lane never valid; yl_pos = jb << 16 | jh << 8 | jw
   if constexpr (LJU >= 0) {
     const int rb4 = rowblk >> 2;
 #pragma unroll
@@ -324,8 +326,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
       const int e = i * 512 + tid;
       const int cc = fast_div(e, g.mg_ewq4);
       const int g4 = e - cc * (g.eWq >> 2);
-      xl_ok[i] = e < rb4 && cc < CB && c0 + cc < g.Cx;
-      xl_off[i] = (cc * g.sT * sHW + 4 * g4) * 4;
+      const bool ok = e < rb4 && cc < CB && c0 + cc < g.Cx;
+      xl_off[i] = ok ? (cc * g.sT * sHW + 4 * g4) * 4 : -1;
       xl_col[i] = 4 * g4;
     }
 #pragma unroll
@@ -335,9 +337,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
       const int pp = (q4 - o * (PP / 4)) * 4;
       const int jw = pp & JWm, r = pp >> g.ljw;
       const int jh = r & JHm, jb = r >> g.ljh;
-      yl_ok[i] = q4 < 64 * PP / 4 && pp < NPIX && o0 + o < g.Co;
-      yl_off[i] = (((jb * g.Co + o) * g.nT) * nHW + jh * g.nW + jw) * 4;
-      yl_jb[i] = jb; yl_jh[i] = jh; yl_jw[i] = jw;
+      const bool ok = q4 < 64 * PP / 4 && pp < NPIX && o0 + o < g.Co;
+      yl_off[i] = ok ? (((jb * g.Co + o) * g.nT) * nHW + jh * g.nW + jw) * 4 : -1;
+      yl_pos[i] = (jb << 16) | (jh << 8) | jw;
     }
   }
   auto issue_fast = [&](int tile, int bufoff) {
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
     int xv[NXI];
 #pragma unroll
     for (int i = 0; i < NXI; ++i)
-      xv[i] = (xl_ok[i] && (unsigned)(sw0 + xl_col[i]) < (unsigned)g.sW) ? xl_off[i] + sw0 * 4 : -16;
+      xv[i] = (xl_off[i] >= 0 && (unsigned)(sw0 + xl_col[i]) < (unsigned)g.sW) ? xl_off[i] + sw0 * 4 : -16;
     for (int prow = 0; prow < nprow; ++prow) {
       const int jb = prow / g.eH, eh = prow - jb * g.eH;
       const int b = j0b + jb, h = sh0 + eh;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
     const int ysoff = (((j0b * g.Co + o0) * g.nT + tt) * nHW + j0h * g.nW + j0w) * 4;
 #pragma unroll
     for (int i = 0; i < NYI; ++i) {
-      const bool ok = yl_ok[i] && j0b + yl_jb[i] < g.B && j0h + yl_jh[i] < g.nH && j0w + yl_jw[i] < g.nW;
+      const bool ok = yl_off[i] >= 0 && j0b + (yl_pos[i] >> 16) < g.B && j0h + ((yl_pos[i] >> 8) & 255) < g.nH && j0w + (yl_pos[i] & 255) < g.nW;
       if (i * 512 + wbase < 64 * PP / 4) dma_b128(rs_y, smem_la + 4u * (ybo + (i * 512 + wbase) * 4), ok ? yl_off[i] : -16, ysoff);
     }
   };
@@ -433,59 +435,106 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
         const int jh = pr & JHm, jb = pr >> g.ljh;
 #pragma unroll
         for (int b = 0; b < 3; ++b)
-          xb[rr][b] = cur + (wm * 32 + l31) * g.eWq + ((jb * g.eH + jh + b) * rowblk + 4 * cu0 + 4 + 2 * lhi);
+          xb[rr][b] = cur + (wm * 32 + l31) * g.eWq +
+                      ((jb * g.eH + SX * jh + b) * rowblk + (SX == 1 ? 4 * cu0 + 4 + 2 * lhi : 8 * cu0 + 2 + 4 * lhi));
       }
       const float* ybp = cur + YOFF + (wn * 32 + l31) * PP + (kh * NU * 4 + 2 * lhi);
-      float2 c01[3], c23[3], n01[3], n23[3], yc, yn;
-      float pr3[3], npr3[3];
-      auto load_unit = [&](int uu, float2 (&w01)[3], float2 (&w23)[3], float (&wp)[3], float2& yy) {
-        const int rr = uu / UPR, cu = uu % UPR;
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          w01[b] = *reinterpret_cast<const float2*>(xb[rr][b] + 4 * cu);
-          w23[b] = *reinterpret_cast<const float2*>(xb[rr][b] + 4 * cu + 2);
-          if (cu == 0) wp[b] = xb[rr][b][-1];                    // (lo: x[p-1], hi: x[p+1]) at a row start
-        }
-        yy = *reinterpret_cast<const float2*>(ybp + 4 * uu);
-      };
-      if (nu > 0) {
-        load_unit(0, c01, c23, pr3, yc);
-#pragma unroll
-        for (int uu = 0; uu < NU; ++uu) {
-          if (uu + 1 < NU) load_unit(uu + 1, n01, n23, npr3, yn);
+      if constexpr (SX == 1) {
+        float2 c01[3], c23[3], n01[3], n23[3], yc, yn;
+        float pr3[3], npr3[3];
+        auto load_unit = [&](int uu, float2 (&w01)[3], float2 (&w23)[3], float (&wp)[3], float2& yy) {
+          const int rr = uu / UPR, cu = uu % UPR;
 #pragma unroll
           for (int b = 0; b < 3; ++b) {
-            acc[b * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pr3[b], yc.x, acc[b * 3 + 0], 0, 0, 0);
-            acc[b * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c01[b].x, yc.x, acc[b * 3 + 1], 0, 0, 0);
-            acc[b * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(c01[b].y, yc.x, acc[b * 3 + 2], 0, 0, 0);
-            acc[b * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c01[b].x, yc.y, acc[b * 3 + 0], 0, 0, 0);
-            acc[b * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c01[b].y, yc.y, acc[b * 3 + 1], 0, 0, 0);
-            acc[b * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(c23[b].x, yc.y, acc[b * 3 + 2], 0, 0, 0);
+            w01[b] = *reinterpret_cast<const float2*>(xb[rr][b] + 4 * cu);
+            w23[b] = *reinterpret_cast<const float2*>(xb[rr][b] + 4 * cu + 2);
+            if (cu == 0) wp[b] = xb[rr][b][-1];                    // (lo: x[p-1], hi: x[p+1]) at a row start
           }
-          // pin the interleave: the next unit's LDS reads ride in this unit's MFMA gaps
-          if (uu + 1 < NU) {
-            constexpr int NL = 7;
-            const int extra = ((uu + 1) % UPR == 0) ? 3 : 0;
+          yy = *reinterpret_cast<const float2*>(ybp + 4 * uu);
+        };
+        if (nu > 0) {
+          load_unit(0, c01, c23, pr3, yc);
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            if (extra) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            } else {
-              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            }
-          }
-          if (uu + 1 < NU) {
+          for (int uu = 0; uu < NU; ++uu) {
+            if (uu + 1 < NU) load_unit(uu + 1, n01, n23, npr3, yn);
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-              pr3[b] = ((uu + 1) % UPR == 0) ? npr3[b] : c23[b].y;
-              c01[b] = n01[b]; c23[b] = n23[b];
+              acc[b * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pr3[b], yc.x, acc[b * 3 + 0], 0, 0, 0);
+              acc[b * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c01[b].x, yc.x, acc[b * 3 + 1], 0, 0, 0);
+              acc[b * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(c01[b].y, yc.x, acc[b * 3 + 2], 0, 0, 0);
+              acc[b * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c01[b].x, yc.y, acc[b * 3 + 0], 0, 0, 0);
+              acc[b * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c01[b].y, yc.y, acc[b * 3 + 1], 0, 0, 0);
+              acc[b * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(c23[b].x, yc.y, acc[b * 3 + 2], 0, 0, 0);
             }
-            yc = yn;
+            // pin the interleave: the next unit's LDS reads ride in this unit's MFMA gaps
+            if (uu + 1 < NU) {
+              constexpr int NL = 7;
+              const int extra = ((uu + 1) % UPR == 0) ? 3 : 0;
+#pragma unroll
+              for (int i = 0; i < NL; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              }
+              if (extra) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+              } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+              }
+            }
+            if (uu + 1 < NU) {
+#pragma unroll
+              for (int b = 0; b < 3; ++b) {
+                pr3[b] = ((uu + 1) % UPR == 0) ? npr3[b] : c23[b].y;
+                c01[b] = n01[b]; c23[b] = n23[b];
+              }
+              yc = yn;
+            }
+          }
+        }
+      } else {
+        // stride 2: group gq of a unit = pixels (4cu + gq) on lanes 0-31 and (4cu + gq + 2) on lanes 32-63
+        float2 xa0[2][3], xa1[2][3], na0[2][3], na1[2][3], yc, yn;
+        auto load_unit2 = [&](int uu, float2 (&w0)[2][3], float2 (&w1)[2][3], float2& yy) {
+          const int rr = uu / UPR, cu = uu % UPR;
+#pragma unroll
+          for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+              w0[gq][b] = *reinterpret_cast<const float2*>(xb[rr][b] + 8 * cu + 2 * gq);         // (-, c0)
+              w1[gq][b] = *reinterpret_cast<const float2*>(xb[rr][b] + 8 * cu + 2 * gq + 2);     // (c1, c2)
+            }
+          yy = *reinterpret_cast<const float2*>(ybp + 4 * uu);
+        };
+        if (nu > 0) {
+          load_unit2(0, xa0, xa1, yc);
+#pragma unroll
+          for (int uu = 0; uu < NU; ++uu) {
+            if (uu + 1 < NU) load_unit2(uu + 1, na0, na1, yn);
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq) {
+              const float yv = gq ? yc.y : yc.x;
+#pragma unroll
+              for (int b = 0; b < 3; ++b) {
+                acc[b * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0[gq][b].y, yv, acc[b * 3 + 0], 0, 0, 0);
+                acc[b * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1[gq][b].x, yv, acc[b * 3 + 1], 0, 0, 0);
+                acc[b * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1[gq][b].y, yv, acc[b * 3 + 2], 0, 0, 0);
+              }
+            }
+            if (uu + 1 < NU) {
+#pragma unroll
+              for (int i = 0; i < 13; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              }
+              __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+#pragma unroll
+              for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) { xa0[gq][b] = na0[gq][b]; xa1[gq][b] = na1[gq][b]; }
+              yc = yn;
+            }
           }
         }
       }
@@ -558,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
     }
     __syncthreads();
     if (kh == 0) {
-#pragma unroll
+#pragma unroll 1                                           // (unrolled, KS = 4 keeps 3 x 64 partner values live and spills)
       for (int g2 = 0; g2 < KS - 1; ++g2) {
         const float* src = smem + ((g2 * 2 * CT + wtile) * TCH * 16 << 6) + lane;
 #pragma unroll
@@ -714,9 +763,15 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
       // window inner loop (3x3, stride 1 in h and w, pad 1 in w, 16-B x image): P2I_WGRAD_WINDOW=0 keeps the per-tap reads
       static const int window_on = getenv("P2I_WGRAD_WINDOW") ? atoi(getenv("P2I_WGRAD_WINDOW")) : 1;
       const int lju = ilog2(jw) - 2;
-      const bool window = window_on && CBh == 64 && g.tpg == 9 && y4 && g.x4 && d->sh == 1 && d->sw == 1 && d->pw == 1 && d->kw == 3 && lju >= 1 && lju <= 3 && g.rowblk <= 4096;
+      const bool win_shape = window_on && g.tpg == 9 && y4 && g.x4 && d->pw == 1 && d->kw == 3 && d->kh == 3 && lju >= 1 && lju <= 3 && g.rowblk <= 4096;
+      const bool window = win_shape && d->sh == 1 && d->sw == 1;                    // stride 1: CB 64 or 32
+      const bool window2 = win_shape && d->sh == 2 && d->sw == 2 && CBh == 32;      // stride 2 (its x image only fits with CB = 32)
       if (window && CBh == 64)
         kern = lju == 3 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 64, 3> : (lju == 2 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 64, 2> : (wk_t)wgrad_dma_kernel<NPIX, 9, true, 64, 1>);
+      else if (window)
+        kern = lju == 3 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 32, 3> : (lju == 2 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 32, 2> : (wk_t)wgrad_dma_kernel<NPIX, 9, true, 32, 1>);
+      else if (window2)
+        kern = lju == 3 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 32, 3, 2> : (lju == 2 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 32, 2, 2> : (wk_t)wgrad_dma_kernel<NPIX, 9, true, 32, 1, 2>);
       else if (CBh == 64) kern = g.tpg == 9 ? (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 64> : (wk_t)wgrad_dma_kernel<NPIX, 9, false, 64>)
                                        : (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 1, true, 64> : (wk_t)wgrad_dma_kernel<NPIX, 1, false, 64>);
       else kern = g.tpg == 9 ? (y4 ? (wk_t)wgrad_dma_kernel<NPIX, 9, true, 32> : (wk_t)wgrad_dma_kernel<NPIX, 9, false, 32>)
