@@ -428,6 +428,13 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s) {
 
 using namespace p2i;
 
+#ifdef P2I_STAMP
+namespace p2i { __device__ unsigned long long* p2i_stamp_buf = nullptr; }
+extern "C" int p2i_debug_set_stamp(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(p2i::p2i_stamp_buf), &buf, sizeof(buf));
+}
+#endif
+
 extern "C" int p2i_conv_last_plan(int* out6) {
   if (!out6) return P2I_EINVAL;
   for (int i = 0; i < 6; ++i) out6[i] = g_last_plan[i];

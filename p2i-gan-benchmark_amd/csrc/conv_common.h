@@ -45,6 +45,52 @@ __device__ __forceinline__ void dma_b128(const v4i32 rsrc, unsigned lds_addr, in
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+
+// Epilogue of one 32x32 accumulator tile (16 registers per lane: dest channel o_r = o_base + (r&3) + 8*(r>>2) + 4*lhi, one dest
+// position per lane): v = act(acc + bias); v += residual; v *= act'(mask).  The 16 residual / mask loads of the tile are issued
+// TOGETHER from clamped addresses and masked afterwards: loads under a per-element condition (`if (res) v += res[di]`) make
+// hipcc branch around each one and wait for it before the next -- 64 serialised HBM round trips per lane, measured at 50-60k
+// cycles per workgroup on the generator's dgrad launches (a quarter of the kernel).
+__device__ __forceinline__ void epilogue_tile16(const f32x16& acc, int o_base, int lhi, int Cm, bool pv, size_t pos_off, size_t chan_stride,
+                                                const float* __restrict__ bias, int act_epi, const float* __restrict__ res,
+                                                const float* __restrict__ mask_y, int mask_act, float* __restrict__ dst) {
+  // two batches of 8 with 32-bit element offsets (tensors are < 2^31 elements: check_desc) and a scheduling fence per batch: without
+  // the fence hipcc hoists the loads of EVERY tile of the workgroup to the top and the register allocation grows by ~100
+#pragma unroll
+  for (int h8 = 0; h8 < 2; ++h8) {
+    int di[8];
+    bool ok[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = h8 * 8 + k;
+      const int o = o_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      ok[k] = pv && o < Cm;
+      di[k] = ok[k] ? (int)((size_t)o * chan_stride + pos_off) : 0;
+    }
+    float rv[8], mv[8];
+    if (res) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) rv[k] = res[di[k]];
+    }
+    if (mask_y) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) mv[k] = mask_y[di[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = h8 * 8 + k;
+      const int o = o_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      float v = acc[r];
+      if (bias) v += bias[o < Cm ? o : 0];
+      v = act_apply(v, act_epi);
+      if (res) v += rv[k];
+      if (mask_y) v = act_grad(v, mv[k], mask_act);
+      if (ok[k]) dst[di[k]] = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 static inline void pick_tile_dims(int NPIX, int B, int nT, int nH, int nW, int& jb, int& jt, int& jh, int& jw) {
   jw = pow2_ceil(nW); if (jw > 32) jw = 32;
   int rem = NPIX / jw;

@@ -7,6 +7,11 @@ namespace p2i {
 
 struct TileCfg { int MB, NPIX, WM, CK; };
 
+#ifdef P2I_STAMP
+// diagnostic build (tools/build_stamp.sh): per-wave cycle sums of the chunk loop's phases; never defined in the product build
+extern __device__ unsigned long long* p2i_stamp_buf;
+#endif
+
 // ------------------------------------------------------------------------------------ DMA-pipelined patch GEMM
 // Same tiling and MFMA loop as patch_gemm_kernel, but the K-chunks are double-buffered in LDS and
 // filled by LDS-DMA (`buffer_load_dword{,x4} ... lds`): no staging VGPRs, no ds_write, and chunk k+1 is
@@ -46,6 +51,10 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
   const int BUFSZ = WSZ + PTp;
 
   constexpr int NTH = 256 * KG;
+#ifdef P2I_STAMP
+  unsigned long long st_entry;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_entry) :: "memory");
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kg = tid >> 8;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -211,12 +220,30 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
     for (int t = 0; t < NT; ++t) toffs[t] = c_tap_off[t];
   }
   const int nchunks = (g.Ck + CK - 1) / CK;
+#ifdef P2I_STAMP
+  // diagnostic build only (tools/stamp_conv.py): where a chunk iteration spends its cycles, per wave
+  unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_mfma = 0, st_t0, st_t1;
+#define P2I_STAMP_NOW(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  unsigned long long st_begin; P2I_STAMP_NOW(st_begin);
+#endif
   issue(0, buf0_off);
   for (int k = 0; k < nchunks; ++k) {
+#ifdef P2I_STAMP
+    P2I_STAMP_NOW(st_t0);
+#endif
     dma_wait_all();                                  // this wave's DMA share of chunk k has landed ...
+#ifdef P2I_STAMP
+    P2I_STAMP_NOW(st_t1); st_wait += st_t1 - st_t0;
+#endif
     __syncthreads();                                 // ... and everybody else's; buffer (k+1)&1 is free
+#ifdef P2I_STAMP
+    P2I_STAMP_NOW(st_t0); st_bar += st_t0 - st_t1;
+#endif
     float* cur = buf0 + (k & 1) * BUFSZ;
     if (k + 1 < nchunks) issue((k + 1) * CK, buf0_off + ((k + 1) & 1) * BUFSZ);
+#ifdef P2I_STAMP
+    P2I_STAMP_NOW(st_t1); st_issue += st_t1 - st_t0;
+#endif
     const float* lw = cur + lhi * MB + wm * TM * 32 + l31;
     const float* lp = cur + WSZ;
     // software pipeline over taps: tap t+1's operands (TM + TN ds_read_b32 per channel pair) are in flight while
@@ -272,8 +299,20 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
         }
       }
     }
+#ifdef P2I_STAMP
+    P2I_STAMP_NOW(st_t0); st_mfma += st_t0 - st_t1;
+#endif
   }
 
+#ifdef P2I_STAMP
+  if (p2i_stamp_buf && (threadIdx.x & 63) == 0) {
+    unsigned long long st_end; P2I_STAMP_NOW(st_end);
+    unsigned long long* o = p2i_stamp_buf + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * (NTH / 64) + (threadIdx.x >> 6)) * 8;
+    o[0] = st_wait; o[1] = st_bar; o[2] = st_issue; o[3] = st_mfma; o[4] = st_end - st_begin; o[5] = st_begin;
+    o[6] = st_begin - st_entry;
+  }
+  unsigned long long st_loop_end; P2I_STAMP_NOW(st_loop_end);
+#endif
   if constexpr (KG == 2) {                           // combine the two wave groups' partial tiles through LDS
     __syncthreads();
     float* red = smem + ((wave * TM * TN * 16) << 6) + lane;
@@ -305,22 +344,18 @@ __global__ __launch_bounds__(256 * KG) void patch_gemm_dma_kernel(const PatchGeo
     const bool pv = gb < g.B && gt < c_nT && gh < c_nH && gw < c_nW;
     const int sp = (gt * g.oT + c_pT) * dHW + (gh * g.oH + c_pH) * g.dW + gw * g.oW + c_pW;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (pv && o < g.Cm) {
-          float v = acc[i][f][r];
-          if (g.bias) v += g.bias[o];
-          v = act_apply(v, g.act_epi);
-          const size_t di = ((size_t)(gb * g.Cm + o)) * g.dT * dHW + sp;
-          if (g.res) v += g.res[di];
-          if (g.mask_y) v = act_grad(v, g.mask_y[di], g.mask_act);
-          g.dst[di] = v;
-        }
-      }
-    }
+    for (int i = 0; i < TM; ++i)
+      epilogue_tile16(acc[i][f], o0 + (wm * TM + i) * 32, lhi, g.Cm, pv, (size_t)gb * g.Cm * g.dT * dHW + sp, (size_t)g.dT * dHW,
+                      g.bias, g.act_epi, g.res, g.mask_y, g.mask_act, g.dst);
   }
+#ifdef P2I_STAMP
+  if (p2i_stamp_buf && (threadIdx.x & 63) == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long st_x; P2I_STAMP_NOW(st_x);
+    unsigned long long* o = p2i_stamp_buf + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * (NTH / 64) + (threadIdx.x >> 6)) * 8;
+    o[7] = st_x - st_loop_end;
+  }
+#endif
 }
 
 template <int MB, int NPIX, int WM, int CK, int NT, int KG>

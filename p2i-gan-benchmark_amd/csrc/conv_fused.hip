@@ -252,19 +252,9 @@ __global__ __launch_bounds__(256) void patch_gemm_fused_kernel(const PatchGeom g
       const bool pv = gb < g.B && gt < c_nT && gh < c_nH && gw < c_nW;
       const int sp = (gt * g.oT + c_pT) * dHW + (gh * g.oH + c_pH) * g.dW + gw * g.oW + c_pW;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = o0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (pv && o < g.Cm) {
-            float v = acc[q][i][f][r];
-            const size_t di = ((size_t)(gb * g.Cm + o)) * g.dT * dHW + sp;
-            if (g.res) v += g.res[di];
-            if (g.mask_y) v = act_grad(v, g.mask_y[di], g.mask_act);
-            g.dst[di] = v;
-          }
-        }
-      }
+      for (int i = 0; i < TM; ++i)
+        epilogue_tile16(acc[q][i][f], o0 + (wm * TM + i) * 32, lhi, g.Cm, pv, (size_t)gb * g.Cm * g.dT * dHW + sp, (size_t)g.dT * dHW,
+                        nullptr, P2I_ACT_NONE, g.res, g.mask_y, g.mask_act, g.dst);
     }
   }
 }
