@@ -184,6 +184,21 @@ def _doconv_of(holder):      # BasicConv holder -> DOConv params
     return holder.main[0]
 
 
+import os as _os
+
+SIDE_WGRAD = _os.environ.get("P2I_SIDE_WGRAD", "1") != "0"
+
+
+def _side_of(net, device):
+    """The network's side stream (ops.SideStream) for weight-gradient kernels, or None when disabled."""
+    if not SIDE_WGRAD:
+        return None
+    sd = getattr(net, "_side", None)
+    if sd is None or sd.stream.device != device:
+        sd = net._side = ops.SideStream(device)
+    return sd
+
+
 def _grad_target(prm, inplace):
     """The parameter's view of the flat gradient buffer when gradients are written in place (TrainEngine), else None."""
     return prm.grad if inplace else None
@@ -282,12 +297,22 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False):
     if inplace and (getattr(net, "_arena_buf", None) is None or net._arena_buf.numel() < net._arena_numel() or net._arena_buf.device != dout.device):
         net._arena_buf = torch.empty(net._arena_numel(), device=dout.device, dtype=torch.float32)
     arena = ops.ZeroArena(net._arena_numel(), dout.device, buf=net._arena_buf if inplace else None)
+    side = _side_of(net, dout.device) if inplace else None       # weight-gradient kernels beside the data-gradient chain
+
+    def wgrad(spec, x, dy, **kw):
+        if side is None:
+            return ops.conv_wgrad(spec, x, dy, arena=arena, **kw)
+        tgt = arena.take(spec.wp_f_shape())                        # carve on the main thread of control: the arena is not stream-safe
+        return side.run(lambda: ops.conv_wgrad(spec, x, dy, dwp_out=tgt, **kw), x, dy)
+
     dz = dout.reshape(b, t, h, w).contiguous().float()
     # ---- ConvsOut (grouped 1x1, dense-lowered) + tanh
     spec_out = _spec2d(BASE_CH, t, 1)
     cout = _doconv_of(net.ConvsOut[0])
     dz = ops.act_bwd(dz, S["z"], ACT_TANH)                      # * (1 - z^2): prologue-free kernels below
-    dwp, _ = ops.conv_wgrad(spec_out, S["h0"], dz, arena=arena)
+    dwp, _ = wgrad(spec_out, S["h0"], dz)
+    if side is not None:
+        side.join()
     gw, _ = ops.doconv_fold_bwd(dwp, *cout.tensors(), t, BASE_CH, 4, 1, out=(cout.W.grad, None) if inplace else None)
     if not inplace:
         grads[id(cout.W)] = gw
@@ -300,13 +325,15 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False):
         pend = []                                    # (packed weight gradient, layer): folded back in two launches per level
         for rb, (hin, y1, w1d, w2d) in zip(reversed(list(blocks)), reversed(S["rec"][lvl])):
             c1, c2 = _doconv_of(rb.main[0]), _doconv_of(rb.main[1])
-            dwp2, _ = ops.conv_wgrad(spec, y1, dh, arena=arena)
+            dwp2, _ = wgrad(spec, y1, dh)
             pend.append((dwp2, c2))
             dy1 = ops.conv_dgrad(spec, dh, w2d, tuple(y1.shape), mask_y=y1, mask_act=ACT_RELU)   # * relu'(y1) fused
-            dwp1, _ = ops.conv_wgrad(spec, hin, dy1, arena=arena)
+            dwp1, _ = wgrad(spec, hin, dy1)
             pend.append((dwp1, c1))
             dh = ops.conv_dgrad(spec, dy1, w1d, tuple(hin.shape), add=dh)                     # + skip path
         outs = ([cv.W.grad for _, cv in pend], [cv.D.grad for _, cv in pend]) if inplace else None
+        if side is not None:
+            side.join()                               # the level's weight gradients are complete
         dWs, dDs = ops.doconv_fold_bwd_batched([g_ for g_, _ in pend], [cv.tensors() for _, cv in pend], ch, ch, outs=outs)
         if not inplace:
             for (_, cv), dW_, dD_ in zip(pend, dWs, dDs):
@@ -319,7 +346,9 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False):
         cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
         spec = _spec2d(cin_, cout_, 1)
         dr = ops.act_bwd(dr, r, ACT_RELU)                       # * relu'(r) once, for wgrad and dgrad
-        dwp, db = ops.conv_wgrad(spec, u, dr, want_bias=True, arena=arena, db_out=_grad_target(up.proj.bias, inplace))
+        dwp, db = wgrad(spec, u, dr, want_bias=True, db_out=_grad_target(up.proj.bias, inplace))
+        if side is not None:
+            side.join()
         gw_ = ops.weight_unpack_grad(dwp, up.proj.weight.reshape(cout_, cin_, 1), out=_grad_target(up.proj.weight, inplace))
         du = ops.conv_dgrad(spec, dr, wpd, tuple(u.shape))
         dx, dpos = ops.upmod_bwd(hin, up.pos, du, dpos_out=_grad_target(up.pos, inplace))
@@ -342,7 +371,9 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False):
     # ---- Convsin (grouped 3x3 + repeat_interleave skip, dense-lowered with centre identity)
     spec_in = _spec2d(t, BASE_CH, 3)
     cin = _doconv_of(net.Convsin[0])
-    dwp, _ = ops.conv_wgrad(spec_in, S["idw"], dx_, arena=arena)
+    dwp, _ = wgrad(spec_in, S["idw"], dx_)
+    if side is not None:
+        side.join()
     gW, gD = ops.doconv_fold_bwd(dwp, *cin.tensors(), BASE_CH, t, 4, 3, out=(cin.W.grad, cin.D.grad) if inplace else None)
     if not inplace:
         grads[id(cin.W)], grads[id(cin.D)] = gW, gD
@@ -547,6 +578,7 @@ def discriminator_backward(net: "P2IDiscriminator", ctx, dfused, need_x: bool, n
         if inplace and (getattr(net, "_arena_buf", None) is None or net._arena_buf.numel() < tot or net._arena_buf.device != dfused.device):
             net._arena_buf = torch.empty(tot, device=dfused.device, dtype=torch.float32)
         arena = ops.ZeroArena(tot, dfused.device, buf=net._arena_buf if inplace else None)
+    side = _side_of(net, dfused.device) if (inplace and arena is not None) else None
 
     def branch_bwd(layers, specs, recs, dy, base, first_add=None):
         # dy arrives already multiplied by act'(y_n): the dgrad of layer n+1 applies it in its epilogue
@@ -554,7 +586,12 @@ def discriminator_backward(net: "P2IDiscriminator", ctx, dfused, need_x: bool, n
         for n in reversed(range(len(layers))):
             m, spec, rc = layers[n], specs[n], recs[n]
             if needs[2 * (base + n)] or needs[2 * (base + n) + 1]:
-                dwp, db = ops.conv_wgrad(spec, rc["x"], dy, want_bias=True, arena=arena, db_out=_grad_target(m.bias, inplace))
+                if side is None:
+                    dwp, db = ops.conv_wgrad(spec, rc["x"], dy, want_bias=True, arena=arena, db_out=_grad_target(m.bias, inplace))
+                else:
+                    tgt = arena.take(spec.wp_f_shape())
+                    dwp, db = side.run(lambda sp=spec, xx=rc["x"], gg=dy, tt=tgt, bb=m.bias.grad: ops.conv_wgrad(
+                        sp, xx, gg, want_bias=True, dwp_out=tt, db_out=bb), rc["x"], dy)
                 wo = m.weight_orig
                 pend.append((base + n, dwp, wo.reshape(wo.shape[0], wo.shape[1], -1), rc, wo.shape, m))
                 gb[base + n] = db
@@ -568,6 +605,8 @@ def discriminator_backward(net: "P2IDiscriminator", ctx, dfused, need_x: bool, n
     add3 = dx_add.reshape(b, c, t, h, w).contiguous() if (dx_add is not None and need_x) else None
     dx3 = branch_bwd(l3, net.specs3d, r3, d3, len(l2), first_add=add3)
     dx = branch_bwd(l2, net.specs2d, r2, d2, 0, first_add=dx3.view(b, t * c, h, w) if dx3 is not None else None)
+    if side is not None:
+        side.join()
     if pend:                  # d(weight_orig) through weight / sigma for every layer, in two launches
         outs = [p_[5].weight_orig.grad for p_ in pend] if inplace else None
         dws = ops.weight_unpack_grad_batched([p_[1] for p_ in pend], [p_[2] for p_ in pend], [p_[2] for p_ in pend],

@@ -131,6 +131,37 @@ def _wgrad_scratch(device):
     return buf
 
 
+class SideStream:
+    """A second HIP stream for work that nothing on the main stream waits for until a join: the weight-gradient kernels of a
+    backward pass (each needs only tensors the data-gradient chain has already produced, and its result is consumed once per
+    level).  Run beside the data-gradient chain they fill each other's kernel tails (single-round grids: ~10 us of ramp / drain /
+    launch gap per kernel) and hide the wgrad slice-reduce kernels.  Dependencies are HIP events; tensors handed to the side
+    stream are kept alive until the join (the caching allocator would otherwise hand their memory to the main stream)."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device)
+        self.keep = []
+        self.pending = False
+
+    def run(self, fn, *tensors):
+        ev = torch.cuda.Event()
+        ev.record()                                    # everything enqueued on the main stream so far (producers of `tensors`)
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            out = fn()
+        self.keep.extend(tensors)
+        self.pending = True
+        return out
+
+    def join(self):
+        if self.pending:
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self.pending = False
+        self.keep.clear()
+
+
 def pad32(n: int) -> int:
     return (n + 31) // 32 * 32
 
@@ -253,7 +284,8 @@ class ZeroArena:
         return t
 
 
-def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False, arena: Optional["ZeroArena"] = None, db_out=None):
+def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False, arena: Optional["ZeroArena"] = None, db_out=None,
+               dwp_out=None):
     """Packed weight gradient dwp_f [ntaps][cin][pad32(cout)] (+ bias gradient).  db_out: caller-owned (cout,) tensor the bias
     gradient is ADDED to (e.g. the parameter's view of the flat gradient buffer)."""
     lib = _hip.load()
@@ -266,7 +298,11 @@ def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False,
         raise RuntimeError("conv_wgrad: y_act shape mismatch")
     if db_out is not None and (tuple(db_out.shape) != (spec.cout,) or not want_bias):
         raise RuntimeError("conv_wgrad: db_out must be (cout,) and want_bias set")
-    if arena is not None:
+    if dwp_out is not None:                      # caller-owned, zeroed packed-gradient target
+        if tuple(dwp_out.shape) != spec.wp_f_shape() or (want_bias and db_out is None):
+            raise RuntimeError("conv_wgrad: dwp_out shape mismatch (and a bias gradient needs db_out with it)")
+        dwp, db = dwp_out, db_out
+    elif arena is not None:
         dwp = arena.take(spec.wp_f_shape())
         db = db_out if db_out is not None else (arena.take((spec.cout,)) if want_bias else None)
     else:
