@@ -11,6 +11,9 @@
  *  - every pointer is a DEVICE pointer to contiguous fp32 (or int32 where stated); the caller
  *    (PyTorch) owns all memory including workspaces; the library never allocates or frees;
  *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*), never syncs;
+ *  - state kept by the library: none that a result depends on.  Per calling THREAD it remembers the tile plan of the last
+ *    conv / wgrad launch (p2i_conv_last_plan / p2i_wgrad_last_plan, diagnostics) and the scratch pointers of a running
+ *    p2i_conv_*_x6 / p2i_conv_wgrad_ws call; tuning switches (P2I_* environment variables) are read once per process;
  *  - return value: 0 on success, negative P2I_E* on a rejected argument, positive = hipError_t
  *    of a failed launch.  Nothing throws across the ABI;
  *  - activations are NC(T)HW; a 2-D tensor is the T == 1 case of the 5-D one.

@@ -259,8 +259,7 @@ static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, h
     t.eH = (jh - 1) * g.mH + rng[1] + 1;
     t.eW = (jw - 1) * g.mW + rng[2] + 1;
     // 16-B patch DMA: rows and tile origins 16-B aligned
-    const char* v4_env = getenv("P2I_CONV_V4");            // read per call: tools/v4_check.py toggles it in-process
-    const int v4_off = v4_env ? (atoi(v4_env) == 0) : 0;
+    static const int v4_off = getenv("P2I_CONV_V4") ? (atoi(getenv("P2I_CONV_V4")) == 0) : 0;   // read once per process
     bool same_lo_w = true;                                  // merged classes may share the aligned origin only if their w windows start alike
     for (int q = 1; q < ncls; ++q) same_lo_w = same_lo_w && lo[q][2] == lo[0][2];
     t.v4 = (!v4_off && same_lo_w && (g.sW & 3) == 0 && ((jw * g.mW) & 3) == 0) ? 1 : 0;   // any source multiplier: rows are contiguous

@@ -731,8 +731,8 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
     const int PPh = y4 ? NPIX + 4 : NPIX + 1;
     g.eWq = g.eW | 1;
     {
-      const char* e4 = getenv("P2I_WGRAD_X4");
-      g.x4 = (!(e4 && atoi(e4) == 0) && (d->Wi & 3) == 0 && ((jw * d->sw) & 3) == 0) ? 1 : 0;
+      static const int x4_off = getenv("P2I_WGRAD_X4") ? (atoi(getenv("P2I_WGRAD_X4")) == 0) : 0;
+      g.x4 = (!x4_off && (d->Wi & 3) == 0 && ((jw * d->sw) & 3) == 0) ? 1 : 0;
       g.x4sh = 0;
       if (g.x4) {
         g.x4sh = (((-d->pw) % 4) + 4) % 4;
@@ -757,7 +757,7 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
     else {
       g.mg_ewq = magic_u16(g.eWq); g.mg_pp = magic_u16(PPh);
       g.x_bytes = (unsigned)xb; g.dy_bytes = (unsigned)yb;
-      { const char* e = getenv("P2I_WGRAD_DBG"); g.dbg = e ? atoi(e) : 0; }
+      { static const int dbg_env = getenv("P2I_WGRAD_DBG") ? atoi(getenv("P2I_WGRAD_DBG")) : 0; g.dbg = dbg_env; }
       typedef void (*wk_t)(const WgradGeom);
       wk_t kern;
       // window inner loop (3x3, stride 1 in h and w, pad 1 in w, 16-B x image): P2I_WGRAD_WINDOW=0 keeps the per-tap reads

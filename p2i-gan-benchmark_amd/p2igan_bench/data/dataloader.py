@@ -75,7 +75,7 @@ class P2IDataModule:
         idx = torch.randperm(n, generator=torch.Generator().manual_seed(seed)).tolist()
         return Subset(ds, idx[:n - nv]), Subset(ds, idx[n - nv:])
 
-    def _loader(self, ds, shuffle, bs):
+    def _loader(self, ds, shuffle, bs, drop_last=None):
         if ds is None:
             return None
         base = ds.dataset if isinstance(ds, Subset) else ds
@@ -84,16 +84,32 @@ class P2IDataModule:
         return DataLoader(ds, batch_size=bs, shuffle=shuffle and sampler is None, sampler=sampler, num_workers=self.num_workers,
                           pin_memory=self.pin_memory, persistent_workers=self.num_workers > 0 and self.persistent_workers,
                           prefetch_factor=self.prefetch_factor if self.num_workers > 0 else None, collate_fn=collate,
-                          drop_last=self.world > 1)
+                          drop_last=(self.world > 1) if drop_last is None else drop_last,
+                          worker_init_fn=_WorkerSeed(self.cfg.get("seed", 42), self.rank) if self.num_workers > 0 else None)
 
     def train_dataloader(self):
         return self._loader(self.train_dataset, True, self.cfg["train"]["batch_size"])
 
     def val_dataloader(self):
-        return self._loader(self.valid_dataset, self.valid_shuffle, self.cfg["train"]["batch_size"])
+        # evaluation splits keep their tail batch on every rank (the trainer all-reduces (sum, count))
+        return self._loader(self.valid_dataset, self.valid_shuffle, self.cfg["train"]["batch_size"], drop_last=False)
 
     def test_dataloader(self):
-        return self._loader(self.test_dataset, self.test_shuffle, 1)
+        return self._loader(self.test_dataset, self.test_shuffle, 1, drop_last=False)
+
+
+class _WorkerSeed:
+    """worker_init_fn: numpy's and python's generators (mask draws, crop offsets) seeded per (rank, worker)."""
+
+    def __init__(self, seed, rank):
+        self.seed, self.rank = seed, rank
+
+    def __call__(self, worker_id):
+        import random
+        import numpy as np
+        s = (self.seed + 1000003 * self.rank + 7919 * (worker_id + 1)) % (2 ** 32)
+        random.seed(s)
+        np.random.seed(s)
 
 
 def _collate_variable(batch):

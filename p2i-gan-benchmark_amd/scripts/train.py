@@ -50,9 +50,12 @@ def load_config(path: Path):
         return json.load(f)
 
 
-def seed_everything(seed: int):
-    random.seed(seed)
-    np.random.seed(seed)
+def seed_everything(seed: int, rank: int = 0):
+    """train.py:78-82.  Under data parallelism the mask / crop generators (create_mask draws from np.random, Dataset_ZarrTrain
+    from random) get seed + rank so that the ranks of a step see different masks and crops; torch's generator keeps the common
+    seed, so every rank builds identical initial weights (they are broadcast from rank 0 anyway)."""
+    random.seed(seed + rank)
+    np.random.seed(seed + rank)
     torch.manual_seed(seed)
 
 
@@ -89,15 +92,22 @@ class _Tracker:
 class Trainer:
     def __init__(self, cfg, rank=0, world=1, local=0):
         self.cfg, self.rank, self.world = cfg, rank, world
-        seed_everything(cfg.get("seed", 42))
+        seed_everything(cfg.get("seed", 42), rank)
         if not torch.cuda.is_available():
             raise RuntimeError("the MI355X path needs a GPU: there is no CPU fallback")
         self.device = torch.device("cuda", local)
         torch.cuda.set_device(self.device)
         dm = P2IDataModule(cfg, rank, world)
         self.train_loader, self.val_loader = dm.train_dataloader(), dm.val_dataloader()
+        self.test_loader = dm.test_dataloader()
         tr = cfg.get("train", {})
         self.run_validation = bool(tr.get("use_validation", True))
+        # train.py:111,164: the reference stores use_test / test_interval and builds the test loader but never runs it; here the
+        # flags drive a periodic pass over the test events (rec loss on the first 16 frames of each), every test_interval epochs
+        self.run_test = bool(tr.get("use_test", True))
+        self.test_interval = int(tr.get("test_interval", 20))
+        logging.info("Data loaders ready | train=%s, val=%s, test=%s", len(self.train_loader),
+                     len(self.val_loader) if self.val_loader is not None else 0, len(self.test_loader) if self.test_loader is not None else 0)
         self.generator = build_generator(cfg).to(self.device)
         self.discriminator = build_discriminator(cfg).to(self.device) if cfg["loss"].get("use_gan", 0) else None
         self.engine = TrainEngine(self.generator, self.discriminator, cfg, distributed=world > 1)
@@ -119,6 +129,23 @@ class Trainer:
             return list(ops.assemble_batch(fr.contiguous(), mk.contiguous()))
         return [t.permute(0, 1, 4, 2, 3).contiguous().to(self.device, non_blocking=True) for t in batch]   # train.py:468-473
 
+    def _evaluate_rec_loss(self, loader, max_frames=None):
+        """train.py:369-382 on the HIP path; under data parallelism (sum, count) are all-reduced so that every rank (and the
+        best.pt decision on rank 0) sees the loss over the whole split.  Returns (mean loss, number of batches)."""
+        tot = torch.zeros(2, dtype=torch.float64, device=self.device)
+        for batch in loader:
+            fr, mk, ms = self._batch(batch)
+            if max_frames is not None and fr.shape[1] > max_frames:      # test events are full-length: first window only
+                fr, mk, ms = (t[:, :max_frames].contiguous() for t in (fr, mk, ms))
+            if fr.shape[1] != self.generator.length:
+                continue
+            tot[0] += self.engine.eval_rec_loss(fr, mk, ms).double()
+            tot[1] += 1
+        if self.world > 1:
+            torch.distributed.all_reduce(tot)
+        nb = int(tot[1])
+        return (float(tot[0]) / nb if nb else float("nan")), nb
+
     def train(self, tracker):
         for epoch in range(1, self.max_epochs + 1):
             if hasattr(self.train_loader.sampler, "set_epoch"):
@@ -126,7 +153,8 @@ class Trainer:
             run, steps = None, 0
             for batch in self.train_loader:
                 out = self.engine.train_step(*self._batch(batch))
-                run = out["loss_g"] if run is None else run + out["loss_g"]       # stays on the device
+                # stays on the device; cloned because a graph-replayed step returns the same output tensors every call
+                run = out["loss_g"].clone() if run is None else run + out["loss_g"]
                 steps += 1
                 self.global_step += 1
                 if self.global_step % self.log_every == 0 and self.rank == 0:       # the only host sync of the loop
@@ -141,13 +169,16 @@ class Trainer:
             logging.info("Epoch %d completed | train_loss=%.4f | global_step=%d", epoch, train_loss, self.global_step)
             val_loss = None
             if self.run_validation and self.val_loader is not None:
-                tot, nb = 0.0, 0
-                for batch in self.val_loader:
-                    tot += float(self.engine.eval_rec_loss(*self._batch(batch)))
-                    nb += 1
-                val_loss = tot / max(1, nb)
-                tracker.metric("val/loss", val_loss, self.global_step)
-                logging.info("Validation done | val_loss=%.4f", val_loss)
+                vl, nb = self._evaluate_rec_loss(self.val_loader)
+                if nb:                                      # an empty split must not pin best.pt at 0.0
+                    val_loss = vl
+                    tracker.metric("val/loss", val_loss, self.global_step)
+                    logging.info("Validation done | val_loss=%.4f (%d batches)", val_loss, nb)
+            if self.run_test and self.test_loader is not None and self.test_interval > 0 and epoch % self.test_interval == 0:
+                tl, nb = self._evaluate_rec_loss(self.test_loader, max_frames=self.generator.length)
+                if nb:
+                    tracker.metric("test/loss", tl, self.global_step)
+                    logging.info("Test pass | test_loss=%.4f (%d events)", tl, nb)
             if self.rank == 0:
                 ck = self.engine.checkpoint(epoch, self.global_step)
                 torch.save(ck, self.save_dir / "latest.pt")
