@@ -313,6 +313,7 @@ int run_patch_gemm_fused(PatchGeom g, const ClassSpec* css, int ncls, int* plan6
   g.eW = (jw - 1) + hi[2] - lo[2] + 1;
   {
     static const int v4_off = getenv("P2I_CONV_V4") ? (atoi(getenv("P2I_CONV_V4")) == 0) : 0;
+    g.v4 = (!v4_off && (g.sW & 3) == 0 && jw >= 4) ? 1 : 0;
     g.v4sh = 0;
     if (g.v4) {
       g.v4sh = ((lo[2] % 4) + 4) % 4;
