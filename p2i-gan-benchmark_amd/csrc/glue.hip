@@ -171,22 +171,27 @@ __device__ __forceinline__ void ac_src(int o, float scale, int S, int& i0, int& 
   i1 = i0 + (i0 < S - 1 ? 1 : 0);
   l1 = src - (float)i0;
 }
-// x (BC, Sh, Sw) -> u (BC, 2Sh, 2Sw); pos (2Sh, 2Sw)
-__global__ void upmod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos, float* u, int BC, int Sh, int Sw) {
+// x (BC, Sh, Sw) -> u (BC, 2Sh, 2Sw); pos (2Sh, 2Sw).  Thread = one output pixel for a chunk of channels (blockIdx.y): the
+// bilinear taps and the modulation 1 + (2 sigmoid(pos) - 1) depend on the pixel only and are computed once, not per channel.
+__global__ __launch_bounds__(256) void upmod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos, float* u, int BC, int Sh, int Sw,
+                                                       int chunk) {
   const int Oh = 2 * Sh, Ow = 2 * Sw;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= Oh * Ow) return;
   const float sch = (float)(Sh - 1) / (float)(Oh - 1), scw = (float)(Sw - 1) / (float)(Ow - 1);
-  const size_t n = (size_t)BC * Oh * Ow;
-  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-    const int ox = idx % Ow, oy = (idx / Ow) % Oh;
-    const size_t bc = idx / ((size_t)Ow * Oh);
-    int y0, y1, x0, x1; float ly, lx;
-    ac_src(oy, sch, Sh, y0, y1, ly);
-    ac_src(ox, scw, Sw, x0, x1, lx);
-    const float* px = x + bc * Sh * Sw;
-    const float v = (1.f - ly) * ((1.f - lx) * px[y0 * Sw + x0] + lx * px[y0 * Sw + x1]) +
-                    ly * ((1.f - lx) * px[y1 * Sw + x0] + lx * px[y1 * Sw + x1]);
-    const float pm = 2.f / (1.f + expf(-pos[oy * Ow + ox])) - 1.f;
-    u[idx] = v + v * pm;
+  const int ox = pix % Ow, oy = pix / Ow;
+  int y0, y1, x0, x1; float ly, lx;
+  ac_src(oy, sch, Sh, y0, y1, ly);
+  ac_src(ox, scw, Sw, x0, x1, lx);
+  const float pm = 2.f / (1.f + expf(-pos[pix])) - 1.f;
+  const int i00 = y0 * Sw + x0, i01 = y0 * Sw + x1, i10 = y1 * Sw + x0, i11 = y1 * Sw + x1;
+  const int bc0 = blockIdx.y * chunk, bc1 = min(BC, bc0 + chunk);
+  const size_t SS = (size_t)Sh * Sw, OO = (size_t)Oh * Ow;
+#pragma unroll 4
+  for (int bc = bc0; bc < bc1; ++bc) {
+    const float* px = x + bc * SS;
+    const float v = (1.f - ly) * ((1.f - lx) * px[i00] + lx * px[i01]) + ly * ((1.f - lx) * px[i10] + lx * px[i11]);
+    u[bc * OO + pix] = v + v * pm;
   }
 }
 // dpos[y,x] += sum_{bc in chunk} du * v * 2 s (1-s);   grid.y = bc chunks
@@ -211,33 +216,47 @@ __global__ void upmod_bwd_pos_kernel(const float* __restrict__ x, const float* _
   const float sg = 1.f / (1.f + expf(-pos[pix]));
   atomicAdd(dpos + pix, acc * 2.f * sg * (1.f - sg));
 }
-// dx[bc, yi, xi] = sum over the output pixels that sample (yi, xi) of weight * du * (1 + posm)
-__global__ void upmod_bwd_x_kernel(const float* __restrict__ pos, const float* __restrict__ du, float* dx, int BC, int Sh, int Sw) {
+// dx[bc, yi, xi] = sum over the output pixels that sample (yi, xi) of weight * du * (1 + posm).  Thread = one INPUT pixel for a
+// chunk of channels: the <= 6 x 6 (weight * modulation) factors are computed once per thread (they held an expf and two
+// source-index computations per output sample and channel before), the channel loop is loads and FMAs only.
+__global__ __launch_bounds__(256) void upmod_bwd_x_kernel(const float* __restrict__ pos, const float* __restrict__ du, float* dx, int BC, int Sh, int Sw,
+                                                         int chunk) {
   const int Oh = 2 * Sh, Ow = 2 * Sw;
+  const int pin = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pin >= Sh * Sw) return;
   const float sch = (float)(Sh - 1) / (float)(Oh - 1), scw = (float)(Sw - 1) / (float)(Ow - 1);
-  const size_t n = (size_t)BC * Sh * Sw;
-  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-    const int xi = idx % Sw, yi = (idx / Sw) % Sh;
-    const size_t bc = idx / ((size_t)Sw * Sh);
-    const int ylo = max(0, 2 * yi - 2), yhi = min(Oh - 1, 2 * yi + 3);
-    const int xlo = max(0, 2 * xi - 2), xhi = min(Ow - 1, 2 * xi + 3);
-    const float* g = du + bc * Oh * Ow;
-    float acc = 0.f;
-    for (int oy = ylo; oy <= yhi; ++oy) {
-      int y0, y1; float ly;
-      ac_src(oy, sch, Sh, y0, y1, ly);
-      const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
-      if (wy == 0.f) continue;
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        int x0, x1; float lx;
-        ac_src(ox, scw, Sw, x0, x1, lx);
-        const float wx = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
-        if (wx == 0.f) continue;
-        const float pm = 2.f / (1.f + expf(-pos[oy * Ow + ox])) - 1.f;
-        acc += wy * wx * g[oy * Ow + ox] * (1.f + pm);
-      }
+  const int xi = pin % Sw, yi = pin / Sw;
+  float wy[6], wx[6];
+  int oyv[6], oxv[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const int oy = 2 * yi - 2 + a, ox = 2 * xi - 2 + a;
+    int i0, i1; float l;
+    wy[a] = 0.f; wx[a] = 0.f;
+    oyv[a] = min(max(oy, 0), Oh - 1); oxv[a] = min(max(ox, 0), Ow - 1);
+    if (oy >= 0 && oy < Oh) { ac_src(oy, sch, Sh, i0, i1, l); wy[a] = (i0 == yi ? 1.f - l : 0.f) + (i1 == yi ? l : 0.f); }
+    if (ox >= 0 && ox < Ow) { ac_src(ox, scw, Sw, i0, i1, l); wx[a] = (i0 == xi ? 1.f - l : 0.f) + (i1 == xi ? l : 0.f); }
+  }
+  float wt[6][6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const float w = wy[a] * wx[b];
+      wt[a][b] = w != 0.f ? w * (2.f / (1.f + expf(-pos[oyv[a] * Ow + oxv[b]]))) : 0.f;     // 1 + (2 sigmoid - 1)
     }
-    dx[idx] = acc;
+  const int bc0 = blockIdx.y * chunk, bc1 = min(BC, bc0 + chunk);
+  const size_t SS = (size_t)Sh * Sw, OO = (size_t)Oh * Ow;
+  for (int bc = bc0; bc < bc1; ++bc) {
+    const float* g = du + bc * OO;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      if (wy[a] == 0.f) continue;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) acc += wt[a][b] * g[oyv[a] * Ow + oxv[b]];
+    }
+    dx[bc * SS + pin] = acc;
   }
 }
 
@@ -433,8 +452,12 @@ extern "C" int p2i_pooldup_bwd(const float* x, const float* dy, float* dx, int B
 }
 extern "C" int p2i_upmod_fwd(const float* x, const float* pos, float* u, int B, int C, int S, int S2w, void* stream) {
   P2I_REQUIRE(x && pos && u, "null pointer");
-  const int64_t n = (int64_t)B * C * 4 * S * S2w;
-  hipLaunchKernelGGL(upmod_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, pos, u, B * C, S, S2w);
+  {
+    const int BC = B * C, npix = 4 * S * S2w;
+    int chunk = BC;                                  // enough (pixel tile, channel chunk) blocks to fill the chip ~8 times
+    while (chunk > 8 && (long long)ceil_div(npix, 256) * ceil_div(BC, chunk) < 2048) chunk = (chunk + 1) / 2;
+    hipLaunchKernelGGL(upmod_fwd_kernel, dim3(ceil_div(npix, 256), ceil_div(BC, chunk)), dim3(256), 0, (hipStream_t)stream, x, pos, u, BC, S, S2w, chunk);
+  }
   return launch_status();
 }
 extern "C" int p2i_upmod_bwd(const float* x, const float* pos, const float* du, float* dx, float* dpos, int B, int C, int S,
@@ -448,8 +471,12 @@ extern "C" int p2i_upmod_bwd(const float* x, const float* pos, const float* du, 
                        BC, S, S2w, chunk);
   }
   if (dx) {
-    const int64_t n = (int64_t)BC * S * S2w;
-    hipLaunchKernelGGL(upmod_bwd_x_kernel, dim3(grid_for(n)), dim3(256), 0, s, pos, du, dx, BC, S, S2w);
+    {
+      const int npin = S * S2w;
+      int chunk2 = BC;
+      while (chunk2 > 8 && (long long)ceil_div(npin, 256) * ceil_div(BC, chunk2) < 2048) chunk2 = (chunk2 + 1) / 2;
+      hipLaunchKernelGGL(upmod_bwd_x_kernel, dim3(ceil_div(npin, 256), ceil_div(BC, chunk2)), dim3(256), 0, s, pos, du, dx, BC, S, S2w, chunk2);
+    }
   }
   return launch_status();
 }
