@@ -1,18 +1,37 @@
-import sys, torch, time
-sys.path.insert(0,"/root/repo/p2i-gan-benchmark_amd")
+"""Full train steps at the other BASELINE.json configurations' per-GPU shapes (sanity: ms/step, frames/s, finite losses, peak memory).
+usage: python tools/sanity_cfgs.py"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "p2i-gan-benchmark_amd"))
 from p2igan_bench.engine import TrainEngine
 from p2igan_bench.models import build_discriminator, build_generator
 from p2igan_bench.utils import seeded
-def run(B,H,W,steps=3):
-    cfg={"seed":1,"model":{"name":"p2igan","in_channels":1},"data":{"train":{"h":H,"w":W,"sample_length":16}},
-         "loss":{"use_gan":1,"gan_loss":"hinge","k1_weight":0.05,"adversarial_weight":0.01},"train":{"optimizer":{"lr":1e-4,"beta1":0.0,"beta2":0.99}}}
-    dev=torch.device("cuda:0"); torch.manual_seed(0)
-    G=build_generator(cfg).to(dev); D=build_discriminator(cfg).to(dev); eng=TrainEngine(G,D,cfg)
-    f,k,m=[t.to(dev) for t in seeded.synthetic_batch(B,16,H,W,seeded.gauge_mask(H,W,79*H*W//16384))]
-    for _ in range(2): out=eng.train_step(f,k,m)
-    torch.cuda.synchronize(); t0=time.perf_counter()
-    for _ in range(steps): out=eng.train_step(f,k,m)
-    torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/steps
-    print(f"B={B} {H}x{W}: {dt*1e3:.1f} ms/step {B*16/dt:.0f} frames/s loss_g={float(out['loss_g']):.4f} loss_d={float(out['loss_d']):.4f} finite={bool(torch.isfinite(out['preds']).all())} mem={torch.cuda.max_memory_allocated()/2**30:.1f} GiB",flush=True)
-    del eng,G,D; torch.cuda.empty_cache()
-run(8,128,128); run(32,128,128); run(16,256,256); run(1,128,128); run(2,64,96)
+
+
+def run(B, H, W, T=16, steps=3, note=""):
+    cfg = {"seed": 1, "model": {"name": "p2igan", "in_channels": 1}, "data": {"train": {"h": H, "w": W, "sample_length": T}},
+           "loss": {"use_gan": 1, "gan_loss": "hinge", "k1_weight": 0.05, "adversarial_weight": 0.01},
+           "train": {"optimizer": {"lr": 1e-4, "beta1": 0.0, "beta2": 0.99}}}
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    G = build_generator(cfg).to(dev); D = build_discriminator(cfg).to(dev); eng = TrainEngine(G, D, cfg)
+    f, k, m = [t.to(dev) for t in seeded.synthetic_batch(B, T, H, W, seeded.gauge_mask(H, W, 79 * H * W // 16384))]
+    for _ in range(2):
+        out = eng.train_step(f, k, m)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        out = eng.train_step(f, k, m)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    print(f"B={B} T={T} {H}x{W} {note}: {dt * 1e3:.1f} ms/step {B * T / dt:.0f} frames/s loss_g={float(out['loss_g']):.4f} "
+          f"loss_d={float(out['loss_d']):.4f} finite={bool(torch.isfinite(out['preds']).all())} mem={torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+    del eng, G, D
+    torch.cuda.empty_cache()
+
+
+run(8, 128, 128, note="configs[1]/[2] per-GPU shape")
+run(32, 128, 128, note="B=32 (north_star stack target batch)")
+run(4, 256, 256, note="configs[3] per-GPU shape (B=16 over 4 GPUs)")
+run(16, 256, 256, note="configs[3] on one GPU")
+run(4, 128, 128, T=32, note="configs[4] per-GPU shape (B=32 over 8 GPUs; T=32 generalisation, parity unpinned)")
+run(1, 128, 128, note="B=1 (launch-bound)")
+run(2, 64, 96, note="non-square")
