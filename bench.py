@@ -272,11 +272,17 @@ def main():
             ops.PROFILE = ops.KernelProfile()
         graph_saved = getattr(eng, "_graph", None)
         eng._graph = None                              # events cannot be recorded inside a replay: eager launches here
+        # The timed region above runs the weight-gradient kernels on a side stream, concurrently with the data-gradient chain; a
+        # launch's duration is then the time it SHARED the chip (wgrad 64-ch: ~135 us overlapped vs ~97 us alone).  The per-kernel
+        # figures below are meant to judge each kernel against the chip's peak, so this pass keeps every launch on the one stream.
+        from p2igan_bench.models import p2igan as _p2igan
+        side_saved, _p2igan.SIDE_WGRAD = _p2igan.SIDE_WGRAD, False
         nprof = max(2, min(5, args.steps))
         for _ in range(nprof):
             eng.train_step(frames, masked, masks)
         summ = ops.PROFILE.summary() if rank == 0 else None
         ops.PROFILE = None
+        _p2igan.SIDE_WGRAD = side_saved
         # BASELINE.json's second figure, "G-step ms" (G fwd, rec loss, D fwd on fake, adv loss, G bwd incl. the
         # dgrad through D, Adam-G): un-instrumented steps with four phase events each
         if rank == 0 and eng.use_gan:
@@ -307,8 +313,9 @@ def main():
             tj = json.load(open(pmc))
             traffic = tj.get("kernels", tj).get(dom)
             traffic_src = tj.get("source")
-        note = ("HIP events bracket the p2i_conv_wgrad_ws call = this kernel + its wgrad_reduce_kernel (rocprofv3 lists them separately)"
-                if dom.startswith("wgrad_dma_kernel") and ops.WGRAD_SLICES else None)
+        note = "instrumented pass: every launch on one stream (P2I_SIDE_WGRAD=0), so a launch's duration is the kernel's own"
+        if dom.startswith("wgrad_dma_kernel") and ops.WGRAD_SLICES:
+            note += "; HIP events bracket the p2i_conv_wgrad_ws call = this kernel + its wgrad_reduce_kernel (rocprofv3 lists them separately)"
         roofline = {"bound": "mfma", "kernel": dom, "note": note, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_us": round(d["seconds"] / d["launches"] * 1e6, 2),

@@ -78,20 +78,21 @@ int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, cons
  * too small: the atomic path of p2i_conv_wgrad. */
 int p2i_conv_wgrad_ws(const p2i_conv_desc* d, const float* x, const float* dy, const float* y_act, int act, float* dwp,
                       float* dbias, float* ws, int64_t ws_floats, void* stream);
-/* Same contracts as p2i_conv_fwd / p2i_conv_dgrad (without the act'(y) prologue), computed on the bf16 matrix
- * pipe with fp32 accuracy: every fp32 operand is split exactly into three bf16 terms and six
- * v_mfma_f32_32x32x16_bf16 products are accumulated in fp32 (conv_x6.hip; error <= 2^-22 per product, the
- * class of an fp32 fma chain).  `wsplit`: caller-owned scratch of 3*ntaps*K*pad32(M) uint16 (K = contraction
- * channels: Cin for fwd, Cout for dgrad; M the other one), overwritten by the call.  Layers outside the x6
- * engine's coverage (K % 16 != 0, tiles that do not fit LDS) run on the fp32-MFMA kernels; wsplit == NULL
- * forces that path. */
+/* Same contracts as p2i_conv_fwd / p2i_conv_dgrad (without the act'(y) prologue).  3x3 stride-1 2-D layers with a contraction
+ * width K % 16 == 0 and enough output tiles to fill the chip are computed on the bf16 matrix pipe with fp32 accuracy
+ * (conv_x6c.hip): every fp32 operand is split exactly into three bf16 terms and six v_mfma_f32_32x32x16_bf16 products are
+ * accumulated in fp32 (the dropped products are <= 2^-23 |a b| each, below the rounding of an fp32 fma chain).  Every other
+ * layer runs on the fp32-MFMA kernels, exactly as p2i_conv_fwd / p2i_conv_dgrad would; the choice is the library's.
+ * `wsplit`: caller-owned scratch of 3*ntaps*K*pad32(M) uint16 (K = contraction channels: Cin for fwd, Cout for dgrad; M the
+ * other one), overwritten by the call; wsplit == NULL forces the fp32-MFMA kernels.  P2I_X6C_MIN_WG (read per call) overrides
+ * the tile-count threshold (default 200 workgroups of 64 x 256 outputs). */
 int p2i_conv_fwd_x6(const p2i_conv_desc* d, const float* x, const float* wp, uint16_t* wsplit, const float* bias,
                     const float* residual, float* y, int act, void* stream);
 int p2i_conv_dgrad_x6(const p2i_conv_desc* d, const float* dy, const float* wp_d, uint16_t* wsplit, const float* dx_add,
                       const float* mask_y, int mask_act, float* dx, void* stream);
 /* tile plan {MB, NPIX, WAVES_M, CK, NT, KG} of the calling thread's most recent fwd/dgrad launch: names the
  * patch_gemm_dma_kernel<MB,NPIX,WAVES_M,CK,NT,KG> instance (NT = -1: the prologue kernel
- * patch_gemm_kernel<MB,NPIX,WAVES_M,CK>; KG = 6: patch_gemm_x6_kernel<TM,TN,WAVES_M>, fields {TM,TN,WAVES_M,TG,ntaps,6})
+ * patch_gemm_kernel<MB,NPIX,WAVES_M,CK>; KG = 7: patch_gemm_x6c_kernel, fields {64,256,1,16,9,7})
  * so that bench.py's roofline can be matched to rocprofv3 rows */
 int p2i_conv_last_plan(int* out6);
 /* same for the most recent p2i_conv_wgrad: {kind (0 wgrad_kernel<64>, 1 wgrad_dma_kernel<64,NTAP,Y4,CB>, 2 c1_wgrad_kernel),

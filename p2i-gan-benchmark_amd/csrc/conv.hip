@@ -212,8 +212,8 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s);
 // Returns 1 if the merged DMA launch is not possible (caller falls back to one launch per class).
 static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, hipStream_t s) {
   if (g.src_y != nullptr || ncls > MAX_CLASSES) return 1;
-  if (const X6Ctx& xc = x6_ctx(); xc.wb != nullptr) {        // inside a p2i_conv_*_x6 call: bf16-split engine first
-    const int rc = run_patch_gemm_x6(g, css, ncls, xc.wb, xc.ntaps_w, g_last_plan, s);
+  if (const X6Ctx& xc = x6_ctx(); xc.wb != nullptr && ncls == 1) {        // inside a p2i_conv_*_x6 call: bf16-split kernel first
+    const int rc = run_patch_gemm_x6c(g, css[0], xc.wb, xc.ntaps_w, g_last_plan, s);
     if (rc != 1) return rc;
   }
   const ClassSpec& c0s = css[0];
@@ -524,15 +524,17 @@ extern "C" int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const flo
 }
 
 
-// ---- exact-fp32 convolution on the bf16 matrix pipe (conv_x6.hip).  `wsplit` is caller-owned scratch of
+// ---- exact-fp32 convolution on the bf16 matrix pipe (conv_x6c.hip).  `wsplit` is caller-owned scratch of
 // 3 * ntaps * K * pad32(M) bf16 (K = contraction channels, M = destination channels of the call) that receives the
-// 3-plane split of `wp`; layers the x6 engine does not cover run on the fp32-MFMA kernels above.
+// 3-plane split of `wp`; layers the bf16-split kernel does not take (x6c_would_take) run on the fp32-MFMA kernels above.
 namespace p2i { int x6_split_weights(const float* wp, uint16_t* wb, int ntaps, int Ck, int CmPad, hipStream_t s); }
+
 
 extern "C" int p2i_conv_fwd_x6(const p2i_conv_desc* d, const float* x, const float* wp, uint16_t* wsplit, const float* bias,
                                const float* residual, float* y, int act, void* stream) {
   if (int e = check_desc(d)) return e;
-  if (wsplit == nullptr || (d->Cin & 15) != 0) return p2i_conv_fwd(d, x, wp, bias, residual, y, act, stream);
+  if (wsplit == nullptr || (d->Cin & 15) != 0 || !x6c_would_take(d, false))
+    return p2i_conv_fwd(d, x, wp, bias, residual, y, act, stream);
   P2I_REQUIRE(wp != nullptr, "null pointer");
   const int nt = d->kt * d->kh * d->kw;
   if (int e = x6_split_weights(wp, wsplit, nt, d->Cin, (d->Cout + 31) / 32 * 32, (hipStream_t)stream)) return e;
@@ -545,7 +547,7 @@ extern "C" int p2i_conv_fwd_x6(const p2i_conv_desc* d, const float* x, const flo
 extern "C" int p2i_conv_dgrad_x6(const p2i_conv_desc* d, const float* dy, const float* wp_d, uint16_t* wsplit, const float* dx_add,
                                  const float* mask_y, int mask_act, float* dx, void* stream) {
   if (int e = check_desc(d)) return e;
-  if (wsplit == nullptr || (d->Cout & 15) != 0 || d->Cin == 1)
+  if (wsplit == nullptr || (d->Cout & 15) != 0 || d->Cin == 1 || !x6c_would_take(d, true))
     return p2i_conv_dgrad(d, dy, nullptr, P2I_ACT_NONE, wp_d, dx_add, mask_y, mask_act, dx, stream);
   P2I_REQUIRE(wp_d != nullptr, "null pointer");
   const int nt = d->kt * d->kh * d->kw;

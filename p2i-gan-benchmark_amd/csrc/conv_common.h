@@ -181,12 +181,14 @@ struct ClassSpec {
   int dt[MAX_TAPS], dh[MAX_TAPS], dw[MAX_TAPS];
 };
 
-// exact-fp32 convolution on the bf16 matrix pipe (conv_x6.hip): set for the duration of a p2i_conv_*_x6 call,
+// exact-fp32 convolution on the bf16 matrix pipe (conv_x6c.hip): set for the duration of a p2i_conv_*_x6 call,
 // points at the 3-plane bf16 split of the packed weights the call is about to use (nullptr: fp32 MFMA path)
 struct X6Ctx { const uint16_t* wb; int ntaps_w; };
 X6Ctx& x6_ctx();
-// returns 1 when no x6 instance fits (caller continues on the fp32-MFMA path)
-int run_patch_gemm_x6(PatchGeom g, const ClassSpec* css, int ncls, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s);
+
+// 3x3 stride-1 2-D layers on the bf16 matrix pipe, chunk/tap-row pipeline (conv_x6c.hip); returns 1 when it does not apply
+int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s);
+bool x6c_would_take(const p2i_conv_desc* d, bool dgrad);
 
 // strided dgrad with the parity classes fused in one workgroup (conv_fused.hip); returns 1 when it does not apply
 int run_patch_gemm_fused(PatchGeom g, const ClassSpec* css, int ncls, int* plan6, hipStream_t s);

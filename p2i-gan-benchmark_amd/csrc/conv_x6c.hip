@@ -1,0 +1,363 @@
+// "x6c": exact-fp32 3x3 stride-1 convolution (forward and data gradient of the generator's DO-Conv stack, 2-D) on the bf16 matrix
+// pipe.  Successor of round 1's conv_x6.hip (removed: slower than the f32 engine on every layer, profiles/README.md "x6 decision"):
+//   * numerics: x = hi + mid + lo (exact 3-way bf16 truncation split of every fp32 operand), six v_mfma_f32_32x32x16_bf16
+//     products (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi) accumulated in fp32; the three dropped products are <= 2^-23 |a b|,
+//     i.e. below fp32 rounding of the term: results agree with the f32-MFMA engine to fp32 rounding (tests/test_ops_gpu.py);
+//   * weights arrive pre-split (wsplit_kernel below) as Wb[plane][tap][k/8][m][8] bf16: one 16-B LDS-DMA element per (m, 8 k's);
+//   * 8 waves (two per SIMD), one 64 x 256 output tile per workgroup, wave = 64 channels x 32 positions (TM 2, TN 1);
+//   * a pipeline STAGE is one kernel row (3 taps) of one 16-channel chunk: its pre-split weights (18 KB) are LDS-DMA'd three
+//     stages ahead into a 4-slot ring; the next chunk's fp32 patch is loaded straight into REGISTERS during the chunk's first
+//     stage (no staging area, no DMA issue), split once per element and written as three bf16 operand planes
+//     [plane][k/8][patch pixel][8 k] into the other plane buffer during the last stage;
+//   * every MFMA operand is one ds_read_b128 at a per-tile base + tap offset; the tap loop is fully unrolled and runs as one
+//     software pipeline across stages: tap t+1's nine operand reads are issued under tap t's twelve MFMAs;
+//   * every vector-memory operation of the loop (weight DMAs and patch loads) is inline asm behind counted s_waitcnt vmcnt(n).
+#include "conv_common.h"
+
+namespace p2i {
+
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_hi16c(float lo_elem, float hi_elem) {
+  return (__float_as_uint(lo_elem) >> 16) | (__float_as_uint(hi_elem) & 0xFFFF0000u);
+}
+__device__ __forceinline__ float trunc_bf16c(float v) { return __uint_as_float(__float_as_uint(v) & 0xFFFF0000u); }
+__device__ __forceinline__ void split8c(const float (&v)[8], u32x4c& hi, u32x4c& mid, u32x4c& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    hi[j] = pack_hi16c(a, b);
+    const float ra = a - trunc_bf16c(a), rb = b - trunc_bf16c(b);          // exact
+    mid[j] = pack_hi16c(ra, rb);
+    const float sa = ra - trunc_bf16c(ra), sb = rb - trunc_bf16c(rb);      // exact
+    lo[j] = pack_hi16c(sa, sb);
+  }
+}
+
+// packed fp32 weights wp[tap][k][CmPad] -> Wb[plane][tap][k/8][CmPad][8] bf16 (planes hi, mid, lo)
+__global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ wp, u32x4c* __restrict__ wb, int ntaps, int Ck, int CmPad) {
+  const int KCt = Ck >> 3;
+  const int total = ntaps * KCt * CmPad;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int m = i % CmPad;
+    const int r = i / CmPad;
+    const int kc = r % KCt, tap = r / KCt;
+    const float* p = wp + ((size_t)tap * Ck + kc * 8) * CmPad + m;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = p[(size_t)q * CmPad];
+    u32x4c h, mi, lo;
+    split8c(v, h, mi, lo);
+    wb[i] = h;
+    wb[total + i] = mi;
+    wb[2 * total + i] = lo;
+  }
+}
+
+X6Ctx& x6_ctx() {
+  static thread_local X6Ctx c{nullptr, 0};
+  return c;
+}
+
+int x6_split_weights(const float* wp, uint16_t* wb, int ntaps, int Ck, int CmPad, hipStream_t s) {
+  const int total = ntaps * (Ck >> 3) * CmPad;
+  const int blocks = total > 0 ? (total + 255) / 256 : 1;
+  hipLaunchKernelGGL(wsplit_kernel, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, s, wp, reinterpret_cast<u32x4c*>(wb), ntaps, Ck, CmPad);
+  return launch_status();
+}
+
+constexpr int X6C_MAXCSL = 384;      // patch pixels per tile (16x16 + halo = 324, 8x32 + halo = 340)
+constexpr int X6C_NI = (2 * X6C_MAXCSL + 511) / 512;
+
+__global__ __launch_bounds__(512) void patch_gemm_x6c_kernel(const PatchGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MB = 64;
+  const int CSl = g.CSl;
+  int* ptab = reinterpret_cast<int*>(smem);                               // [CSl] element offset of patch pixel e, channel 0 (-1: outside)
+  const int ptab_sz = (CSl + 3) & ~3;
+  u32x4c* wbuf = reinterpret_cast<u32x4c*>(smem + ptab_sz);              // [4][3 planes][3 taps][2 k-groups][64 m]: ring, filled 3 stages ahead
+  constexpr int WST = 18 * MB;
+  constexpr int RING = 4, LEAD = 3;                 // a stage is ~1.2 us of MFMAs, an L2 -> LDS DMA ~2 us under load
+  u32x4c* planes = wbuf + RING * WST;                                        // [2][3 planes][2 k-groups][CSl]
+  const int PST = 6 * CSl;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int tile = blockIdx.x;
+  const int tw = tile % g.ntw; tile /= g.ntw;
+  const int th = tile % g.nth;
+  const int tb = tile / g.nth;
+  const int j0b = tb << g.ljb, j0h = th << g.ljh, j0w = tw << g.ljw;
+  const int o0 = blockIdx.y * MB;
+  const int JWm = (1 << g.ljw) - 1, JHm = (1 << g.ljh) - 1;
+  const int sHW = g.sH * g.sW;
+  const int src_h0 = j0h + g.bH, src_w0 = j0w + g.bW;
+  const int KCt = g.Ck >> 3;
+
+  for (int e = tid; e < CSl; e += 512) {
+    const int row = fast_div(e, g.mg_ew);
+    const int ew = e - row * g.eW;
+    const int jb = fast_div(row, g.mg_eh);
+    const int eh = row - jb * g.eH;
+    const int b = j0b + jb, h = src_h0 + eh, w = src_w0 + ew;
+    ptab[e] = (b < g.B && (unsigned)h < (unsigned)g.sH && (unsigned)w < (unsigned)g.sW) ? (b * g.Ck) * sHW + h * g.sW + w : -1;
+  }
+  // this wave's 32 output positions
+  const int pix = wave * 32 + l31;
+  const int pjw = pix & JWm, pjh = (pix >> g.ljw) & JHm, pjb = pix >> (g.ljw + g.ljh);
+  const int lane_base = (pjb * g.eH + pjh) * g.eW + pjw + lhi * CSl;
+  int toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) toff[t] = g.tap_off[t];
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const v4i32 rs_w = make_rsrc(g.wb, g.wb_bytes);
+  const unsigned wbuf_la = lds_base(smem) + 4u * ptab_sz;
+  const int wvoff = (o0 + lane < g.CmPad) ? lane * 16 : -16;
+  __syncthreads();                                                        // ptab visible
+
+  // patch items of this thread: (k-group kg, patch pixel e); 8 channel values each
+  int it_off[X6C_NI], it_dst[X6C_NI];
+#pragma unroll
+  for (int it = 0; it < X6C_NI; ++it) {
+    const int item = it * 512 + tid;
+    const int kg = item >= CSl ? 1 : 0, e = item - kg * CSl;
+    const bool in = item < 2 * CSl;
+    const int po = in ? ptab[e] : -1;
+    it_off[it] = po < 0 ? -1 : po + kg * 8 * sHW;
+    it_dst[it] = in ? kg * CSl + e : -1;
+  }
+  // The patch loads are issued from inline asm like the DMAs, so that EVERY vector-memory operation of the loop is counted by
+  // hand: next to asm DMAs hipcc would wait vmcnt(0) before the first use of a plain load's result and drain the weight ring.
+  // pv is not touched between load_patch and the counted wait in front of split_patch.
+  float pv[X6C_NI][8];
+  int it_voff[X6C_NI];
+#pragma unroll
+  for (int it = 0; it < X6C_NI; ++it) it_voff[it] = (it_off[it] < 0 ? 0 : it_off[it]) * 4;
+  auto load_patch = [&](int c) {
+    const float* sc = g.src + (size_t)c * 16 * sHW;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float* sq = sc + (size_t)q * sHW;
+      const unsigned long long sq_u = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)sq) & 0xffffffffull;
+      const unsigned long long sq_hi = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)sq >> 32));
+      const unsigned long long sbase = sq_u | (sq_hi << 32);
+#pragma unroll
+      for (int it = 0; it < X6C_NI; ++it)
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(pv[it][q]) : "v"(it_voff[it]), "s"(sbase) : "memory");
+    }
+  };
+  auto split_patch = [&](u32x4c* pb) {
+#pragma unroll
+    for (int it = 0; it < X6C_NI; ++it) {
+      if (it_dst[it] < 0) continue;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = it_off[it] < 0 ? 0.f : pv[it][q];
+      u32x4c h, mi, lo;
+      split8c(v, h, mi, lo);
+      pb[it_dst[it]] = h;
+      pb[2 * CSl + it_dst[it]] = mi;
+      pb[4 * CSl + it_dst[it]] = lo;
+    }
+  };
+  // weights of stage (chunk c, kernel row b) -> wbuf[sb]: 18 wave-instructions (plane, tap, k-group) of 64 x 16 B, dealt to the 8 waves
+  auto issue_w = [&](int c, int b, int sb) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int u = wave + 8 * r;
+      if (u < 18) {
+        const int p = u / 6, tl = (u >> 1) % 3, kg = u & 1;
+        const int soff = (((p * g.ntaps_w + g.tap_w[3 * b + tl]) * KCt + 2 * c + kg) * g.CmPad + o0) * 16;
+        dma_b128(rs_w, wbuf_la + 16u * (unsigned)(sb * WST + u * MB), wvoff, soff);
+      }
+    }
+  };
+
+  const int nch = g.Ck >> 4;
+  const int nst = 3 * nch;
+  const int nw_mine = wave < 2 ? 3 : 2;                // this wave's DMA instructions per weight batch
+  constexpr int NPL = 8 * X6C_NI;                      // patch loads per thread and chunk
+  // counted wait: all but the n youngest vector-memory operations of this wave are done (n is wave-uniform, <= 2*3 + 2*NPL)
+  auto wait_vm = [&](int n) {
+#define P2I_WC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+      P2I_WC(0) P2I_WC(1) P2I_WC(2) P2I_WC(3) P2I_WC(4) P2I_WC(5) P2I_WC(6) P2I_WC(7) P2I_WC(8) P2I_WC(9) P2I_WC(10) P2I_WC(11) P2I_WC(12)
+      P2I_WC(13) P2I_WC(14) P2I_WC(15) P2I_WC(16) P2I_WC(17) P2I_WC(18) P2I_WC(19) P2I_WC(20) P2I_WC(21) P2I_WC(22) P2I_WC(23) P2I_WC(24)
+      P2I_WC(25) P2I_WC(26) P2I_WC(27) P2I_WC(28) P2I_WC(29) P2I_WC(30) P2I_WC(31) P2I_WC(32) P2I_WC(33) P2I_WC(34) P2I_WC(35) P2I_WC(36)
+      P2I_WC(37) P2I_WC(38)
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef P2I_WC
+  };
+  auto nwb = [&](int st) { return st < nst ? nw_mine : 0; };
+  // prologue: weights of stages 0 .. LEAD-1, patch of chunk 0
+  load_patch(0);
+#pragma unroll
+  for (int st = 0; st < LEAD; ++st)
+    if (st < nst) issue_w(st / 3, st % 3, st % RING);
+  wait_vm(nwb(0) + nwb(1) + nwb(2));                   // the patch loads (older than the three weight batches) have landed
+  __builtin_amdgcn_sched_barrier(0);
+  split_patch(planes);
+  wait_vm(nwb(1) + nwb(2));                            // weights of stage 0 too
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};            // small terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  // One continuous software pipeline over all taps: tap t+1's nine operand reads are in flight under tap t's twelve MFMAs, ACROSS
+  // stage boundaries too.  The hand-over barrier of stage s+1 (its weights landed, the next chunk's planes written) therefore sits
+  // in front of the LAST tap of stage s, and that tap's MFMAs cover the first reads of stage s+1.  Three operand register sets.
+  u32x4c A[3][2][3], Bv[3][3];
+  auto load_tap = [&](const u32x4c* wsl, const u32x4c* pbp, int tap, int buf) {
+    const int tl = tap % 3;
+    const int to = toff[tap];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      A[buf][0][p] = wsl[((p * 3 + tl) * 2) * MB];
+      A[buf][1][p] = wsl[((p * 3 + tl) * 2) * MB + 32];
+      Bv[buf][p] = pbp[p * 2 * CSl + to];
+    }
+  };
+  auto mfma_tap = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, A[buf][i][PA[q]]), __builtin_bit_cast(bf16x8c, Bv[buf][PB[q]]),
+                                                         acc[i], 0, 0, 0);
+  };
+  auto ilv = [&]() {                                   // 12 MFMAs with the next tap's 9 operand reads in their gaps
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+  };
+  const u32x4c* wlane = wbuf + lhi * MB + l31;
+  load_tap(wlane, planes + lane_base, 0, 0);
+  int s = 0;
+  for (int c = 0; c < nch; ++c) {
+    const u32x4c* pb = planes + (c & 1) * PST + lane_base;
+    const u32x4c* pbn = planes + ((c + 1) & 1) * PST + lane_base;
+    const bool more_c = c + 1 < nch;
+#pragma unroll
+    for (int b = 0; b < 3; ++b, ++s) {
+      // vector-memory operations this wave issues per stage, all at its start and in this order:
+      //   [patch loads of chunk c+1 if b == 0]  [weights of stage s+LEAD]
+      const int sa = s + LEAD;
+      if (b == 0 && more_c) load_patch(c + 1);
+      if (b == 2 && more_c) {
+        // patch loads were issued in stage s-2; younger: the weights issued in stages s-2 and s-1
+        wait_vm(nwb(s - 2 + LEAD) + nwb(s - 1 + LEAD));
+        __builtin_amdgcn_sched_barrier(0);
+        split_patch(planes + ((c + 1) & 1) * PST);     // buffer read last in chunk c-1
+      }
+      if (sa < nst) issue_w(sa / 3, sa % 3, sa % RING);            // slot read last in stage s-1 (complete before its barrier)
+      const u32x4c* wsl = wlane + (s % RING) * WST;
+      __builtin_amdgcn_sched_barrier(0);
+      load_tap(wsl, pb, 3 * b + 1, 1);
+      mfma_tap(0);
+      ilv();
+      __builtin_amdgcn_sched_barrier(0);
+      load_tap(wsl, pb, 3 * b + 2, 2);
+      mfma_tap(1);
+      ilv();
+      __builtin_amdgcn_sched_barrier(0);
+      // stage s+1 needs its weights (issued in stage s-2); everything issued in stages s-1 and s may stay in flight
+      const int p_prev = (b == 1 && more_c) ? NPL : 0;             // stage s-1 was the b == 0 stage of this chunk
+      const int p_this = (b == 0 && more_c) ? NPL : 0;
+      wait_vm(p_prev + nwb(s - 1 + LEAD) + p_this + nwb(sa));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // own tap reads and plane writes done
+      __builtin_amdgcn_s_barrier();
+      if (s + 1 < nst) load_tap(wlane + ((s + 1) % RING) * WST, b == 2 ? pbn : pb, b == 2 ? 0 : 3 * b + 3, 0);
+      mfma_tap(2);
+      ilv();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue (shared with the f32 engine)
+  const int gw = j0w + pjw, gh = j0h + pjh, gb = j0b + pjb;
+  const bool pvld = gb < g.B && gh < g.nH && gw < g.nW;
+  const int dHW = g.dH * g.dW;
+  const size_t pos = (size_t)gb * g.Cm * dHW + (size_t)gh * g.dW + gw;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    epilogue_tile16(acc[i], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, g.bias, g.act_epi, g.res, g.mask_y, g.mask_act, g.dst);
+}
+
+// Fewest workgroups for which the 64 x 256 tile beats the f32 engine's smaller tiles on 256 CUs.  Read per call (not cached) so that
+// the parity tests can send small layers through this kernel (P2I_X6C_MIN_WG=1).
+static int x6c_min_wg() { const char* e = getenv("P2I_X6C_MIN_WG"); return e ? atoi(e) : 200; }
+
+// cheap host-side test used before the weights are split: would run_patch_gemm_x6c take this layer?
+bool x6c_would_take(const p2i_conv_desc* d, bool dgrad) {
+  static const int on = getenv("P2I_CONV_X6C") ? atoi(getenv("P2I_CONV_X6C")) : 1;
+  const int min_wg = x6c_min_wg();
+  if (!on || d->kt != 1 || d->kh != 3 || d->kw != 3 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->Ti != 1 || d->To != 1) return false;
+  const int Ck = dgrad ? d->Cout : d->Cin, Cm = dgrad ? d->Cin : d->Cout;
+  const int nH = dgrad ? d->Hi : d->Ho, nW = dgrad ? d->Wi : d->Wo;
+  if ((Ck & 15) != 0 || Ck < 16) return false;
+  int jb, jt, jh, jw;
+  pick_tile_dims(256, d->B, 1, nH, nW, jb, jt, jh, jw);
+  if (jt != 1 || jb * (jh + 2) * (jw + 2) > X6C_MAXCSL) return false;
+  return (long long)ceil_div(d->B, jb) * ceil_div(nH, jh) * ceil_div(nW, jw) * ceil_div(Cm, 64) >= min_wg;
+}
+
+// returns 1 when the layer is not an x6c case (caller continues with the other engines)
+int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s) {
+  static const int on = getenv("P2I_CONV_X6C") ? atoi(getenv("P2I_CONV_X6C")) : 1;
+  if (!on || wb == nullptr || g.src_y != nullptr || cs.ntaps != 9 || (g.Ck & 15) != 0 || g.Ck < 16) return 1;
+  if (cs.mT != 1 || cs.mH != 1 || cs.mW != 1 || cs.oT != 1 || cs.oH != 1 || cs.oW != 1 || cs.pT || cs.pH || cs.pW) return 1;
+  if (g.sT != 1 || g.dT != 1 || cs.nT != 1) return 1;
+  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  for (int i = 0; i < 9; ++i) {
+    const int d[3] = {cs.dt[i], cs.dh[i], cs.dw[i]};
+    for (int k = 0; k < 3; ++k) {
+      if (i == 0 || d[k] < lo[k]) lo[k] = d[k];
+      if (i == 0 || d[k] > hi[k]) hi[k] = d[k];
+    }
+  }
+  if (lo[0] != 0 || hi[0] != 0 || hi[1] - lo[1] != 2 || hi[2] - lo[2] != 2) return 1;
+  int jb, jt, jh, jw;
+  pick_tile_dims(256, g.B, 1, cs.nH, cs.nW, jb, jt, jh, jw);
+  if (jt != 1) return 1;
+  g.nT = 1; g.nH = cs.nH; g.nW = cs.nW;
+  g.mT = g.mH = g.mW = 1; g.oT = g.oH = g.oW = 1; g.pT = g.pH = g.pW = 0;
+  g.ljb = ilog2(jb); g.ljt = 0; g.ljh = ilog2(jh); g.ljw = ilog2(jw);
+  g.eT = 1; g.eH = jh + 2; g.eW = jw + 2;
+  g.CSl = jb * g.eH * g.eW;
+  if (g.CSl > X6C_MAXCSL) return 1;
+  g.bT = 0; g.bH = lo[1]; g.bW = lo[2];
+  for (int i = 0; i < 9; ++i) {
+    g.tap_w[i] = cs.tw[i];
+    g.tap_off[i] = (cs.dh[i] - lo[1]) * g.eW + (cs.dw[i] - lo[2]);
+  }
+  g.ntaps = 9;
+  g.nth = ceil_div(cs.nH, jh); g.ntw = ceil_div(cs.nW, jw); g.ntt = 1;
+  const int ntb = ceil_div(g.B, jb);
+  const dim3 grid((unsigned)(ntb * g.nth * g.ntw), (unsigned)ceil_div(g.Cm, 64));
+  if ((long long)grid.x * grid.y < x6c_min_wg()) return 1;            // too few workgroups for 256 CUs: the f32 engine's smaller tiles win
+  const unsigned long long sbytes = 4ull * g.B * g.Ck * g.sH * g.sW;
+  if (sbytes >= 0x7FFFFFF0ull) return 1;
+  g.mg_ew = magic_u16(g.eW); g.mg_eh = magic_u16(g.eH);
+  g.wb = wb; g.ntaps_w = ntaps_w;
+  g.wb_bytes = 3u * (unsigned)ntaps_w * (unsigned)g.Ck * (unsigned)g.CmPad * 2u;
+  g.nclass = 1;
+  const size_t lds = sizeof(float) * (size_t)((g.CSl + 3) & ~3) + 16 * (size_t)(4 * 18 * 64 + 2 * 6 * g.CSl);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)patch_gemm_x6c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (plan6) { plan6[0] = 64; plan6[1] = 256; plan6[2] = 1; plan6[3] = 16; plan6[4] = 9; plan6[5] = 7; }
+  hipLaunchKernelGGL(patch_gemm_x6c_kernel, grid, dim3(512), lds, s, g);
+  return launch_status();
+}
+
+}  // namespace p2i

@@ -81,6 +81,8 @@ def _prof_end(e0, kind, spec, desc, stride1):
         _hip.load().p2i_conv_last_plan(plan)
         if plan[5] > 10:
             key = "patch_gemm_fused_kernel<%d, %d, %d, %d, %d> (strided dgrad, %d parity classes per workgroup)" % (plan[0], plan[1], plan[2], plan[3], plan[5] - 10, plan[5] - 10)
+        elif plan[5] == 7:
+            key = "patch_gemm_x6c_kernel (64 x 256 tile, bf16-split x6)"
         elif plan[5] == 6:
             key = "patch_gemm_x6_kernel<%d, %d, %d>%s" % (plan[0], plan[1], plan[2], "" if stride1 else " (strided dgrad classes)")
         elif not stride1:
@@ -92,19 +94,21 @@ def _prof_end(e0, kind, spec, desc, stride1):
     PROFILE.records.append((key, flops, e0, e1))
 
 
-# Convolution engine selection: "f32" (default) = v_mfma_f32_32x32x2_f32 kernels; "x6" = exact-fp32 on the bf16
-# matrix pipe (3-way bf16 split, six MFMA products, csrc/conv_x6.hip; opt-in until it is the faster one).  Both are
-# HIP paths; layers x6 does not cover fall through to the f32 kernels inside the library.
+# Convolution engine selection (forward and data gradient).  "auto" (default): the exact-fp32 bf16-split kernel of csrc/conv_x6c.hip
+# (3-way bf16 split, six v_mfma_f32_32x32x16_bf16 products) on the layers where it is the faster one (3x3 stride-1 2-D layers with
+# >= 200 workgroups: the generator's 64- and 128-channel levels at B=8; measured 63 vs 100 us on the 128-channel level), the
+# v_mfma_f32_32x32x2_f32 kernels everywhere else; the choice is made inside the library (x6c_would_take).  "f32": f32 kernels only.
+# ("x6" is accepted as an alias of "auto".)  Both are HIP paths.
 import os as _os
 
-CONV_ENGINE = _os.environ.get("P2I_CONV_ENGINE", "f32")
+CONV_ENGINE = _os.environ.get("P2I_CONV_ENGINE", "auto")
 _X6_SCRATCH = {}
 
 
 def _x6_scratch(numel: int, device):
     """uint16 scratch for the split weights of ONE conv call, reused by every call on the same stream (the split
     kernel and its consumer are stream-ordered, so the next call may overwrite it)."""
-    if CONV_ENGINE != "x6":
+    if CONV_ENGINE not in ("auto", "x6"):
         return None
     key = (str(device), torch.cuda.current_stream().cuda_stream)
     buf = _X6_SCRATCH.get(key)

@@ -33,6 +33,7 @@ CONV_CASES = [
     ("g3x3_128_s16", 2, 3, 128, 128, (16, 16), (3, 3), (1, 1), (1, 1), "none", False, True),
     ("g3x3_tiny4", 2, 2, 512, 512, (4, 4), (3, 3), (1, 1), (1, 1), "none", False, False),
     ("g3x3_w128", 2, 1, 64, 64, (24, 128), (3, 3), (1, 1), (1, 1), "relu", False, False),
+    ("g3x3_odd", 2, 3, 32, 48, (19, 21), (3, 3), (1, 1), (1, 1), "relu", True, True),     # partial tiles in H, W and channels
     ("proj1x1", 2, 2, 128, 64, (16, 16), (1, 1), (1, 1), (0, 0), "relu", True, True),
     ("d2d_s2_odd", 2, 2, 16, 32, (20, 22), (3, 3), (2, 2), (1, 1), "leaky", True, False),
     ("d2d_s2", 2, 2, 64, 128, (32, 32), (3, 3), (2, 2), (1, 1), "leaky", True, False),
@@ -52,37 +53,53 @@ def _act_cpu(y, act):
     return {"none": lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.2), "tanh": torch.tanh}[act](y)
 
 
-@pytest.fixture(params=["f32", "x6"])
-def engine(request, ops):
-    """Both convolution engines are held to the same oracle: f32-MFMA kernels (default) and the bf16-split x6 kernels."""
+@pytest.fixture(params=["f32", "x6c"])
+def engine(request, ops, monkeypatch):
+    """Both convolution engines are held to the same oracle: the f32-MFMA kernels and the bf16-split kernel (conv_x6c.hip).  The
+    latter only takes layers with >= 200 workgroups by default; P2I_X6C_MIN_WG=1 (read per call) sends the small test layers
+    it covers through it too."""
     old = ops.CONV_ENGINE
-    ops.CONV_ENGINE = request.param
+    ops.CONV_ENGINE = "f32" if request.param == "f32" else "auto"
+    if request.param == "x6c":
+        monkeypatch.setenv("P2I_X6C_MIN_WG", "1")
     yield request.param
     ops.CONV_ENGINE = old
 
 
-def test_x6_engine_is_used(ops):
-    """The x6 engine must really run (not silently fall through) on the generator's 3x3 C->C layers."""
+def _last_plan(ops):
     import ctypes
+    plan = (ctypes.c_int * 6)()
+    ops._hip.load().p2i_conv_last_plan(plan)
+    return tuple(plan)
+
+
+def test_x6c_engine_is_used(ops, monkeypatch):
+    """The bf16-split kernel must really run (not silently fall through) where it claims to: on a layer with >= 200 workgroups
+    by default, on small 3x3 stride-1 layers once the threshold is lowered, and never with the engine set to f32."""
     old = ops.CONV_ENGINE
-    ops.CONV_ENGINE = "x6"
     try:
+        ops.CONV_ENGINE = "auto"
         spec = ops.ConvSpec(64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1))
         wp_f, wp_d = ops.weight_pack(_rand(64, 64, 9, seed=1, scale=0.05).cuda())
-        x = _rand(2, 64, 32, 32, seed=2).cuda()
-        plan = (ctypes.c_int * 6)()
+        xl = _rand(4, 64, 128, 128, seed=2).cuda()                      # 256 tiles of 64 x 256: default threshold
+        yl = ops.conv_fwd(spec, xl, wp_f)
+        assert _last_plan(ops)[5] == 7, _last_plan(ops)
+        x = xl[:2, :, :32, :32].contiguous()
+        ops.conv_fwd(spec, x, wp_f)
+        assert _last_plan(ops)[5] != 7                                  # 8 tiles: f32 engine
+        monkeypatch.setenv("P2I_X6C_MIN_WG", "1")
         y = ops.conv_fwd(spec, x, wp_f)
-        ops._hip.load().p2i_conv_last_plan(plan)
-        assert plan[5] == 6, tuple(plan)
+        assert _last_plan(ops)[5] == 7, _last_plan(ops)
         ops.conv_dgrad(spec, y, wp_d, tuple(x.shape))
-        ops._hip.load().p2i_conv_last_plan(plan)
-        assert plan[5] == 6, tuple(plan)
+        assert _last_plan(ops)[5] == 7, _last_plan(ops)
         ops.CONV_ENGINE = "f32"
         y32 = ops.conv_fwd(spec, x, wp_f)
-        ops._hip.load().p2i_conv_last_plan(plan)
-        assert plan[5] != 6
+        assert _last_plan(ops)[5] != 7
+        yl32 = ops.conv_fwd(spec, xl, wp_f)
+        assert _last_plan(ops)[5] != 7
         # the split drops only products below 2^-23 of a term: both engines agree to fp32 rounding
         assert rel_err(y.cpu().numpy(), y32.cpu().numpy()) < 5e-6
+        assert rel_err(yl.cpu().numpy(), yl32.cpu().numpy()) < 5e-6
     finally:
         ops.CONV_ENGINE = old
 
@@ -111,6 +128,9 @@ def test_conv_fwd_dgrad_wgrad(ops, engine, case):
     wp_f, wp_d = ops.weight_pack(w.detach().to(dev))
     xg = x.detach().to(dev)
     yg = ops.conv_fwd(spec, xg, wp_f, bias.detach().to(dev) if has_bias else None, res.to(dev) if has_res else None, act_code)
+    x6c_layer = engine == "x6c" and nd == 2 and k == (3, 3) and st == (1, 1) and name != "g3x3_w128"    # w128: patch > 384 pixels
+    if x6c_layer and Cin % 16 == 0:
+        assert _last_plan(ops)[5] == 7, (name, _last_plan(ops))
     assert rel_err(yg.cpu().numpy(), out.detach().numpy()) < TOL_OP
 
     # backward: dy_eff = gout * act'(y).  The HIP path gets the post-activation tensor (before residual).
@@ -121,6 +141,8 @@ def test_conv_fwd_dgrad_wgrad(ops, engine, case):
     addt, mk = _rand(*x.shape, seed=6), _rand(*x.shape, seed=7)
     gin = gout * {"none": 1.0, "relu": (y > 0).float(), "leaky": torch.where(y > 0, 1.0, 0.2), "tanh": 1 - y * y}[act]
     dx2 = ops.conv_dgrad(spec, gin.detach().to(dev).contiguous(), wp_d, tuple(x.shape), add=addt.to(dev), mask_y=mk.to(dev), mask_act=ops.ACT_RELU)
+    if x6c_layer and Cout % 16 == 0 and Cin > 1:
+        assert _last_plan(ops)[5] == 7, (name, _last_plan(ops))
     assert rel_err(dx2.cpu().numpy(), ((x.grad + addt) * (mk > 0)).numpy()) < TOL_OP
     # prologue-free weight gradient on the pre-masked gradient (what the model code uses)
     dwp2, db2 = ops.conv_wgrad(spec, xg, gin.detach().to(dev).contiguous(), want_bias=has_bias)
