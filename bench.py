@@ -177,7 +177,10 @@ def stack_b32(dev, batch=32, iters=10):
         levels["C%d@%d" % (C, S)] = row
         del x, dy
     ach = tot_f / tot_s / 1e12
-    return {"what": "generator 3x3 DO-Conv stack, one layer per level, fwd+dgrad+wgrad, B=%d, f32 MFMA" % batch, "bound": "mfma",
+    return {"what": "generator 3x3 DO-Conv stack, one layer per level, fwd+dgrad+wgrad, B=%d; exact-fp32 results; engine %s" % (batch, ops.CONV_ENGINE),
+            "peak_note": "priced against the f32-MFMA peak (157.3 TF).  With engine 'auto' fwd/dgrad run as six bf16 MFMA products per fp32 "
+                         "product (conv_x6c.hip; that pipe's own bound is 2500/6 = 416.7 TF fp32-equivalent) and can exceed it; wgrad is f32 MFMA",
+            "bound": "mfma",
             "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
             "gflop": round(tot_f / 1e9, 1), "ms": round(tot_s * 1e3, 3), "tflops_by_level": levels}
 

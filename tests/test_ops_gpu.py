@@ -128,7 +128,7 @@ def test_conv_fwd_dgrad_wgrad(ops, engine, case):
     wp_f, wp_d = ops.weight_pack(w.detach().to(dev))
     xg = x.detach().to(dev)
     yg = ops.conv_fwd(spec, xg, wp_f, bias.detach().to(dev) if has_bias else None, res.to(dev) if has_res else None, act_code)
-    x6c_layer = engine == "x6c" and nd == 2 and k == (3, 3) and st == (1, 1) and name != "g3x3_w128"    # w128: patch > 384 pixels
+    x6c_layer = engine == "x6c" and nd == 2 and k == (3, 3) and st == (1, 1) and name not in ("g3x3_w128", "g3x3_tiny4")    # those two: patch > 384 pixels, f32 engine
     if x6c_layer and Cin % 16 == 0:
         assert _last_plan(ops)[5] == 7, (name, _last_plan(ops))
     assert rel_err(yg.cpu().numpy(), out.detach().numpy()) < TOL_OP
