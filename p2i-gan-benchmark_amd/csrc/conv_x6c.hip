@@ -67,19 +67,41 @@ int x6_split_weights(const float* wp, uint16_t* wb, int ntaps, int Ck, int CmPad
   return launch_status();
 }
 
-constexpr int X6C_MAXCSL = 384;      // patch pixels per tile (16x16 + halo = 324, 8x32 + halo = 340)
-constexpr int X6C_NI = (2 * X6C_MAXCSL + 511) / 512;
+// Tile variants <NW waves, TM 32-channel tiles per wave>: a workgroup computes (32 TM) channels x (32 NW) positions, wave = 32 TM
+// channels x 32 positions.  <8,2> (64 x 256) is the efficient one (0.75 operand reads per MFMA); <8,1> (32 x 256) gives the
+// 256-channel level (32x32 maps, 128 tiles of 64 x 256 at B = 8) one workgroup per CU: 72 vs 103 us (<8,2>) vs 89 us (f32 engine).
+// Four-wave variants (128 positions, one wave per SIMD) were measured and dropped: 112-230 us on the same layers.
+template <int NW> struct X6cTile {
+  static constexpr int MAXCSL = NW == 8 ? 384 : 256;     // patch pixels per tile (16x16 + halo = 324, 8x32 + halo = 340; 4x32: 204, 8x16: 180)
+  static constexpr int NI = (2 * MAXCSL + 64 * NW - 1) / (64 * NW);
+};
 
-__global__ __launch_bounds__(512) void patch_gemm_x6c_kernel(const PatchGeom g) {
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant); n > 63 cannot happen here
+__device__ __forceinline__ void x6c_wait_vm(int n) {
+#define P2I_WC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    P2I_WC(0) P2I_WC(1) P2I_WC(2) P2I_WC(3) P2I_WC(4) P2I_WC(5) P2I_WC(6) P2I_WC(7) P2I_WC(8) P2I_WC(9) P2I_WC(10) P2I_WC(11) P2I_WC(12)
+    P2I_WC(13) P2I_WC(14) P2I_WC(15) P2I_WC(16) P2I_WC(17) P2I_WC(18) P2I_WC(19) P2I_WC(20) P2I_WC(21) P2I_WC(22) P2I_WC(23) P2I_WC(24)
+    P2I_WC(25) P2I_WC(26) P2I_WC(27) P2I_WC(28) P2I_WC(29) P2I_WC(30) P2I_WC(31) P2I_WC(32) P2I_WC(33) P2I_WC(34) P2I_WC(35) P2I_WC(36)
+    P2I_WC(37) P2I_WC(38) P2I_WC(39) P2I_WC(40) P2I_WC(41) P2I_WC(42) P2I_WC(43) P2I_WC(44) P2I_WC(45) P2I_WC(46) P2I_WC(47) P2I_WC(48)
+    P2I_WC(49) P2I_WC(50) P2I_WC(51) P2I_WC(52) P2I_WC(53) P2I_WC(54) P2I_WC(55) P2I_WC(56) P2I_WC(57) P2I_WC(58) P2I_WC(59) P2I_WC(60)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef P2I_WC
+}
+
+template <int NW, int TM>
+__global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int MB = 64;
+  constexpr int MB = 32 * TM, NTHR = 64 * NW, NI = X6cTile<NW>::NI;
+  constexpr int RING = TM == 2 ? 4 : 6, LEAD = RING - 1;  // a stage is ~1.2 us (TM 2) / ~0.6 us (TM 1) of MFMAs, an L2 -> LDS DMA ~2 us under load
+  constexpr int WST = 18 * MB;                            // 16-B elements of one stage's weights: [3 planes][3 taps][2 k-groups][MB m]
+  constexpr int NWI = 18 * MB / 64;                       // ... = this many 64-lane DMA instructions (TM 1: one covers both k-groups of 32 m)
   const int CSl = g.CSl;
   int* ptab = reinterpret_cast<int*>(smem);                               // [CSl] element offset of patch pixel e, channel 0 (-1: outside)
   const int ptab_sz = (CSl + 3) & ~3;
-  u32x4c* wbuf = reinterpret_cast<u32x4c*>(smem + ptab_sz);              // [4][3 planes][3 taps][2 k-groups][64 m]: ring, filled 3 stages ahead
-  constexpr int WST = 18 * MB;
-  constexpr int RING = 4, LEAD = 3;                 // a stage is ~1.2 us of MFMAs, an L2 -> LDS DMA ~2 us under load
-  u32x4c* planes = wbuf + RING * WST;                                        // [2][3 planes][2 k-groups][CSl]
+  u32x4c* wbuf = reinterpret_cast<u32x4c*>(smem + ptab_sz);              // [RING][WST]: ring, filled LEAD stages ahead
+  u32x4c* planes = wbuf + RING * WST;                                     // [2][3 planes][2 k-groups][CSl]
   const int PST = 6 * CSl;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,7 +117,7 @@ __global__ __launch_bounds__(512) void patch_gemm_x6c_kernel(const PatchGeom g) 
   const int src_h0 = j0h + g.bH, src_w0 = j0w + g.bW;
   const int KCt = g.Ck >> 3;
 
-  for (int e = tid; e < CSl; e += 512) {
+  for (int e = tid; e < CSl; e += NTHR) {
     const int row = fast_div(e, g.mg_ew);
     const int ew = e - row * g.eW;
     const int jb = fast_div(row, g.mg_eh);
@@ -111,22 +133,24 @@ __global__ __launch_bounds__(512) void patch_gemm_x6c_kernel(const PatchGeom g) 
 #pragma unroll
   for (int t = 0; t < 9; ++t) toff[t] = g.tap_off[t];
 
-  f32x16 acc[2];
+  f32x16 acc[TM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const v4i32 rs_w = make_rsrc(g.wb, g.wb_bytes);
   const unsigned wbuf_la = lds_base(smem) + 4u * ptab_sz;
-  const int wvoff = (o0 + lane < g.CmPad) ? lane * 16 : -16;
+  // lane -> (k-group, m) of a weight DMA instruction: TM 2: 64 m of one k-group; TM 1: 32 m of both k-groups
+  const int wl_m = TM == 2 ? lane : l31, wl_kg = TM == 2 ? 0 : lhi;
+  const int wvoff = (o0 + wl_m < g.CmPad) ? (wl_kg * g.CmPad + wl_m) * 16 : -16;
   __syncthreads();                                                        // ptab visible
 
   // patch items of this thread: (k-group kg, patch pixel e); 8 channel values each
-  int it_off[X6C_NI], it_dst[X6C_NI];
+  int it_off[NI], it_dst[NI];
 #pragma unroll
-  for (int it = 0; it < X6C_NI; ++it) {
-    const int item = it * 512 + tid;
+  for (int it = 0; it < NI; ++it) {
+    const int item = it * NTHR + tid;
     const int kg = item >= CSl ? 1 : 0, e = item - kg * CSl;
     const bool in = item < 2 * CSl;
     const int po = in ? ptab[e] : -1;
@@ -136,10 +160,10 @@ __global__ __launch_bounds__(512) void patch_gemm_x6c_kernel(const PatchGeom g) 
   // The patch loads are issued from inline asm like the DMAs, so that EVERY vector-memory operation of the loop is counted by
   // hand: next to asm DMAs hipcc would wait vmcnt(0) before the first use of a plain load's result and drain the weight ring.
   // pv is not touched between load_patch and the counted wait in front of split_patch.
-  float pv[X6C_NI][8];
-  int it_voff[X6C_NI];
+  float pv[NI][8];
+  int it_voff[NI];
 #pragma unroll
-  for (int it = 0; it < X6C_NI; ++it) it_voff[it] = (it_off[it] < 0 ? 0 : it_off[it]) * 4;
+  for (int it = 0; it < NI; ++it) it_voff[it] = (it_off[it] < 0 ? 0 : it_off[it]) * 4;
   auto load_patch = [&](int c) {
     const float* sc = g.src + (size_t)c * 16 * sHW;
 #pragma unroll
@@ -149,13 +173,13 @@ __global__ __launch_bounds__(512) void patch_gemm_x6c_kernel(const PatchGeom g) 
       const unsigned long long sq_hi = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)sq >> 32));
       const unsigned long long sbase = sq_u | (sq_hi << 32);
 #pragma unroll
-      for (int it = 0; it < X6C_NI; ++it)
+      for (int it = 0; it < NI; ++it)
         asm volatile("global_load_dword %0, %1, %2" : "=v"(pv[it][q]) : "v"(it_voff[it]), "s"(sbase) : "memory");
     }
   };
   auto split_patch = [&](u32x4c* pb) {
 #pragma unroll
-    for (int it = 0; it < X6C_NI; ++it) {
+    for (int it = 0; it < NI; ++it) {
       if (it_dst[it] < 0) continue;
       float v[8];
 #pragma unroll
@@ -167,61 +191,59 @@ __global__ __launch_bounds__(512) void patch_gemm_x6c_kernel(const PatchGeom g) 
       pb[4 * CSl + it_dst[it]] = lo;
     }
   };
-  // weights of stage (chunk c, kernel row b) -> wbuf[sb]: 18 wave-instructions (plane, tap, k-group) of 64 x 16 B, dealt to the 8 waves
+  // weights of stage (chunk c, kernel row b) -> wbuf[sb]: NWI wave-instructions of 64 x 16 B, dealt round-robin to the waves
+  constexpr int NWR = (NWI + NW - 1) / NW;
   auto issue_w = [&](int c, int b, int sb) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int u = wave + 8 * r;
-      if (u < 18) {
-        const int p = u / 6, tl = (u >> 1) % 3, kg = u & 1;
+    for (int r = 0; r < NWR; ++r) {
+      const int u = wave + NW * r;
+      if (u < NWI) {
+        // TM 2: u = (plane, tap, k-group); TM 1: u = (plane, tap), the two k-groups ride in the lane halves
+        const int pt = TM == 2 ? u >> 1 : u, kg = TM == 2 ? u & 1 : 0;
+        const int p = pt / 3, tl = pt % 3;
         const int soff = (((p * g.ntaps_w + g.tap_w[3 * b + tl]) * KCt + 2 * c + kg) * g.CmPad + o0) * 16;
-        dma_b128(rs_w, wbuf_la + 16u * (unsigned)(sb * WST + u * MB), wvoff, soff);
+        dma_b128(rs_w, wbuf_la + 16u * (unsigned)(sb * WST + u * 64), wvoff, soff);
       }
     }
   };
 
   const int nch = g.Ck >> 4;
   const int nst = 3 * nch;
-  const int nw_mine = wave < 2 ? 3 : 2;                // this wave's DMA instructions per weight batch
-  constexpr int NPL = 8 * X6C_NI;                      // patch loads per thread and chunk
-  // counted wait: all but the n youngest vector-memory operations of this wave are done (n is wave-uniform, <= 2*3 + 2*NPL)
-  auto wait_vm = [&](int n) {
-#define P2I_WC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    switch (n) {
-      P2I_WC(0) P2I_WC(1) P2I_WC(2) P2I_WC(3) P2I_WC(4) P2I_WC(5) P2I_WC(6) P2I_WC(7) P2I_WC(8) P2I_WC(9) P2I_WC(10) P2I_WC(11) P2I_WC(12)
-      P2I_WC(13) P2I_WC(14) P2I_WC(15) P2I_WC(16) P2I_WC(17) P2I_WC(18) P2I_WC(19) P2I_WC(20) P2I_WC(21) P2I_WC(22) P2I_WC(23) P2I_WC(24)
-      P2I_WC(25) P2I_WC(26) P2I_WC(27) P2I_WC(28) P2I_WC(29) P2I_WC(30) P2I_WC(31) P2I_WC(32) P2I_WC(33) P2I_WC(34) P2I_WC(35) P2I_WC(36)
-      P2I_WC(37) P2I_WC(38)
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-#undef P2I_WC
-  };
+  const int nw_mine = (NWI / NW) + (wave < NWI % NW ? 1 : 0);          // this wave's DMA instructions per weight batch
+  constexpr int NPL = 8 * NI;                                           // patch loads per thread and chunk
   auto nwb = [&](int st) { return st < nst ? nw_mine : 0; };
-  // prologue: weights of stages 0 .. LEAD-1, patch of chunk 0
+  // Vector-memory operations of this wave, in issue order: prologue [P(0)] [W(0)] .. [W(LEAD-1)], then per stage s, all at its
+  // start, [P(chunk+1) if s % 3 == 0 and there is a next chunk] [W(s+LEAD)] (P = NPL patch loads, W = nw_mine weight DMAs).
+  // prologue
   load_patch(0);
 #pragma unroll
   for (int st = 0; st < LEAD; ++st)
     if (st < nst) issue_w(st / 3, st % 3, st % RING);
-  wait_vm(nwb(0) + nwb(1) + nwb(2));                   // the patch loads (older than the three weight batches) have landed
-  __builtin_amdgcn_sched_barrier(0);
-  split_patch(planes);
-  wait_vm(nwb(1) + nwb(2));                            // weights of stage 0 too
+  {
+    int n = 0;
+#pragma unroll
+    for (int st = 0; st < LEAD; ++st) n += nwb(st);
+    x6c_wait_vm(n);                                                     // the patch loads (older than the weight batches) have landed
+    __builtin_amdgcn_sched_barrier(0);
+    split_patch(planes);
+    x6c_wait_vm(n - nwb(0));                                            // weights of stage 0 too
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0};            // small terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-  // One continuous software pipeline over all taps: tap t+1's nine operand reads are in flight under tap t's twelve MFMAs, ACROSS
-  // stage boundaries too.  The hand-over barrier of stage s+1 (its weights landed, the next chunk's planes written) therefore sits
-  // in front of the LAST tap of stage s, and that tap's MFMAs cover the first reads of stage s+1.  Three operand register sets.
-  u32x4c A[3][2][3], Bv[3][3];
+  // One continuous software pipeline over all taps: tap t+1's operand reads are in flight under tap t's MFMAs, ACROSS stage
+  // boundaries too.  The hand-over barrier of stage s+1 (its weights landed, the next chunk's planes written) therefore sits in
+  // front of the LAST tap of stage s, and that tap's MFMAs cover the first reads of stage s+1.  Three operand register sets.
+  u32x4c A[3][TM][3], Bv[3][3];
   auto load_tap = [&](const u32x4c* wsl, const u32x4c* pbp, int tap, int buf) {
     const int tl = tap % 3;
     const int to = toff[tap];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-      A[buf][0][p] = wsl[((p * 3 + tl) * 2) * MB];
-      A[buf][1][p] = wsl[((p * 3 + tl) * 2) * MB + 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) A[buf][i][p] = wsl[((p * 3 + tl) * 2) * MB + 32 * i];
       Bv[buf][p] = pbp[p * 2 * CSl + to];
     }
   };
@@ -229,14 +251,17 @@ __global__ __launch_bounds__(512) void patch_gemm_x6c_kernel(const PatchGeom g) 
 #pragma unroll
     for (int q = 0; q < 6; ++q)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, A[buf][i][PA[q]]), __builtin_bit_cast(bf16x8c, Bv[buf][PB[q]]),
                                                          acc[i], 0, 0, 0);
   };
-  auto ilv = [&]() {                                   // 12 MFMAs with the next tap's 9 operand reads in their gaps
+  auto ilv = [&]() {                                   // a tap's MFMAs with the next tap's operand reads in their gaps
+    constexpr int NR = 3 * TM + 3, NM = 6 * TM;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    for (int i = 0; i < NM; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
   };
   const u32x4c* wlane = wbuf + lhi * MB + l31;
   load_tap(wlane, planes + lane_base, 0, 0);
@@ -247,13 +272,11 @@ __global__ __launch_bounds__(512) void patch_gemm_x6c_kernel(const PatchGeom g) 
     const bool more_c = c + 1 < nch;
 #pragma unroll
     for (int b = 0; b < 3; ++b, ++s) {
-      // vector-memory operations this wave issues per stage, all at its start and in this order:
-      //   [patch loads of chunk c+1 if b == 0]  [weights of stage s+LEAD]
       const int sa = s + LEAD;
       if (b == 0 && more_c) load_patch(c + 1);
       if (b == 2 && more_c) {
         // patch loads were issued in stage s-2; younger: the weights issued in stages s-2 and s-1
-        wait_vm(nwb(s - 2 + LEAD) + nwb(s - 1 + LEAD));
+        x6c_wait_vm(nwb(s - 2 + LEAD) + nwb(s - 1 + LEAD));
         __builtin_amdgcn_sched_barrier(0);
         split_patch(planes + ((c + 1) & 1) * PST);     // buffer read last in chunk c-1
       }
@@ -268,10 +291,19 @@ __global__ __launch_bounds__(512) void patch_gemm_x6c_kernel(const PatchGeom g) 
       mfma_tap(1);
       ilv();
       __builtin_amdgcn_sched_barrier(0);
-      // stage s+1 needs its weights (issued in stage s-2); everything issued in stages s-1 and s may stay in flight
-      const int p_prev = (b == 1 && more_c) ? NPL : 0;             // stage s-1 was the b == 0 stage of this chunk
-      const int p_this = (b == 0 && more_c) ? NPL : 0;
-      wait_vm(p_prev + nwb(s - 1 + LEAD) + p_this + nwb(sa));
+      // stage s+1 needs its weights W(s+1); everything issued after that batch may stay in flight: W(s+2) .. W(s+LEAD), and the
+      // patch loads of the stages s+2-LEAD .. s that start a chunk
+      {
+        int n = 0;
+#pragma unroll
+        for (int j = 2; j <= LEAD; ++j) n += nwb(s + j);
+#pragma unroll
+        for (int j = 0; j <= LEAD - 2; ++j) {
+          const int bj = ((b - j) % 3 + 3) % 3;                     // kernel row of stage s-j
+          if (bj == 0 && s - j >= 0 && (s - j) / 3 + 1 < nch) n += NPL;
+        }
+        x6c_wait_vm(n);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // own tap reads and plane writes done
       __builtin_amdgcn_s_barrier();
       if (s + 1 < nst) load_tap(wlane + ((s + 1) % RING) * WST, b == 2 ? pbn : pb, b == 2 ? 0 : 3 * b + 3, 0);
@@ -287,26 +319,55 @@ __global__ __launch_bounds__(512) void patch_gemm_x6c_kernel(const PatchGeom g) 
   const int dHW = g.dH * g.dW;
   const size_t pos = (size_t)gb * g.Cm * dHW + (size_t)gh * g.dW + gw;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
     epilogue_tile16(acc[i], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, g.bias, g.act_epi, g.res, g.mask_y, g.mask_act, g.dst);
 }
 
-// Fewest workgroups for which the 64 x 256 tile beats the f32 engine's smaller tiles on 256 CUs.  Read per call (not cached) so that
-// the parity tests can send small layers through this kernel (P2I_X6C_MIN_WG=1).
+// Fewest workgroups for which a tile variant is used (256 CUs; below that the next smaller tile, or the f32 engine).  Read per call
+// (not cached) so that the parity tests can send small layers through these kernels (P2I_X6C_MIN_WG=1).
 static int x6c_min_wg() { const char* e = getenv("P2I_X6C_MIN_WG"); return e ? atoi(e) : 200; }
+// P2I_X6C_TILE=<NW><TM> (82, 81) forces one variant (tests, tuning)
+static int x6c_forced() { const char* e = getenv("P2I_X6C_TILE"); return e ? atoi(e) : 0; }
+
+struct X6cVariant { int NW, TM; };
+static const X6cVariant kX6cVariants[] = {{8, 2}, {8, 1}};      // in order of per-CU efficiency
+constexpr int kNX6cVariants = 2;
+
+struct X6cPick { int v, jb, jh, jw, csl; long long wgs; };
+// first variant whose grid fills the chip and whose patch fits; v = -1: none
+static X6cPick x6c_pick(int B, int nH, int nW, int Cm) {
+  const int forced = x6c_forced(), min_wg = x6c_min_wg();
+  for (int v = 0; v < kNX6cVariants; ++v) {
+    const X6cVariant& t = kX6cVariants[v];
+    if (forced && forced != t.NW * 10 + t.TM) continue;
+    int jb, jt, jh, jw;
+    pick_tile_dims(32 * t.NW, B, 1, nH, nW, jb, jt, jh, jw);
+    const int csl = jb * (jh + 2) * (jw + 2);
+    if (jt != 1 || csl > (t.NW == 8 ? X6cTile<8>::MAXCSL : X6cTile<4>::MAXCSL)) continue;
+    const long long wgs = (long long)ceil_div(B, jb) * ceil_div(nH, jh) * ceil_div(nW, jw) * ceil_div(Cm, 32 * t.TM);
+    if (wgs >= min_wg) return X6cPick{v, jb, jh, jw, csl, wgs};
+  }
+  return X6cPick{-1, 0, 0, 0, 0, 0};
+}
 
 // cheap host-side test used before the weights are split: would run_patch_gemm_x6c take this layer?
 bool x6c_would_take(const p2i_conv_desc* d, bool dgrad) {
   static const int on = getenv("P2I_CONV_X6C") ? atoi(getenv("P2I_CONV_X6C")) : 1;
-  const int min_wg = x6c_min_wg();
   if (!on || d->kt != 1 || d->kh != 3 || d->kw != 3 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->Ti != 1 || d->To != 1) return false;
   const int Ck = dgrad ? d->Cout : d->Cin, Cm = dgrad ? d->Cin : d->Cout;
   const int nH = dgrad ? d->Hi : d->Ho, nW = dgrad ? d->Wi : d->Wo;
   if ((Ck & 15) != 0 || Ck < 16) return false;
-  int jb, jt, jh, jw;
-  pick_tile_dims(256, d->B, 1, nH, nW, jb, jt, jh, jw);
-  if (jt != 1 || jb * (jh + 2) * (jw + 2) > X6C_MAXCSL) return false;
-  return (long long)ceil_div(d->B, jb) * ceil_div(nH, jh) * ceil_div(nW, jw) * ceil_div(Cm, 64) >= min_wg;
+  return x6c_pick(d->B, nH, nW, Cm).v >= 0;
+}
+
+template <int NW, int TM>
+static void x6c_launch(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)patch_gemm_x6c_kernel<NW, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((patch_gemm_x6c_kernel<NW, TM>), grid, dim3(64 * NW), lds, s, g);
 }
 
 // returns 1 when the layer is not an x6c case (caller continues with the other engines)
@@ -324,15 +385,15 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
     }
   }
   if (lo[0] != 0 || hi[0] != 0 || hi[1] - lo[1] != 2 || hi[2] - lo[2] != 2) return 1;
-  int jb, jt, jh, jw;
-  pick_tile_dims(256, g.B, 1, cs.nH, cs.nW, jb, jt, jh, jw);
-  if (jt != 1) return 1;
+  const X6cPick pk = x6c_pick(g.B, cs.nH, cs.nW, g.Cm);
+  if (pk.v < 0) return 1;
+  const X6cVariant& tv = kX6cVariants[pk.v];
+  const int jb = pk.jb, jh = pk.jh, jw = pk.jw;
   g.nT = 1; g.nH = cs.nH; g.nW = cs.nW;
   g.mT = g.mH = g.mW = 1; g.oT = g.oH = g.oW = 1; g.pT = g.pH = g.pW = 0;
   g.ljb = ilog2(jb); g.ljt = 0; g.ljh = ilog2(jh); g.ljw = ilog2(jw);
   g.eT = 1; g.eH = jh + 2; g.eW = jw + 2;
-  g.CSl = jb * g.eH * g.eW;
-  if (g.CSl > X6C_MAXCSL) return 1;
+  g.CSl = pk.csl;
   g.bT = 0; g.bH = lo[1]; g.bW = lo[2];
   for (int i = 0; i < 9; ++i) {
     g.tap_w[i] = cs.tw[i];
@@ -341,22 +402,18 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   g.ntaps = 9;
   g.nth = ceil_div(cs.nH, jh); g.ntw = ceil_div(cs.nW, jw); g.ntt = 1;
   const int ntb = ceil_div(g.B, jb);
-  const dim3 grid((unsigned)(ntb * g.nth * g.ntw), (unsigned)ceil_div(g.Cm, 64));
-  if ((long long)grid.x * grid.y < x6c_min_wg()) return 1;            // too few workgroups for 256 CUs: the f32 engine's smaller tiles win
+  const dim3 grid((unsigned)(ntb * g.nth * g.ntw), (unsigned)ceil_div(g.Cm, 32 * tv.TM));
   const unsigned long long sbytes = 4ull * g.B * g.Ck * g.sH * g.sW;
   if (sbytes >= 0x7FFFFFF0ull) return 1;
   g.mg_ew = magic_u16(g.eW); g.mg_eh = magic_u16(g.eH);
   g.wb = wb; g.ntaps_w = ntaps_w;
   g.wb_bytes = 3u * (unsigned)ntaps_w * (unsigned)g.Ck * (unsigned)g.CmPad * 2u;
   g.nclass = 1;
-  const size_t lds = sizeof(float) * (size_t)((g.CSl + 3) & ~3) + 16 * (size_t)(4 * 18 * 64 + 2 * 6 * g.CSl);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)patch_gemm_x6c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  if (plan6) { plan6[0] = 64; plan6[1] = 256; plan6[2] = 1; plan6[3] = 16; plan6[4] = 9; plan6[5] = 7; }
-  hipLaunchKernelGGL(patch_gemm_x6c_kernel, grid, dim3(512), lds, s, g);
+  const int ring = tv.TM == 2 ? 4 : 6;
+  const size_t lds = sizeof(float) * (size_t)((g.CSl + 3) & ~3) + 16 * (size_t)(ring * 18 * 32 * tv.TM + 2 * 6 * g.CSl);
+  if (plan6) { plan6[0] = 32 * tv.TM; plan6[1] = 32 * tv.NW; plan6[2] = 1; plan6[3] = 16; plan6[4] = 9; plan6[5] = 7; }
+  if (tv.TM == 2) x6c_launch<8, 2>(g, grid, lds, s);
+  else x6c_launch<8, 1>(g, grid, lds, s);
   return launch_status();
 }
 

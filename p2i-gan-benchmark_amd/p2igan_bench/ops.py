@@ -82,13 +82,7 @@ def _prof_end(e0, kind, spec, desc, stride1):
         if plan[5] > 10:
             key = "patch_gemm_fused_kernel<%d, %d, %d, %d, %d> (strided dgrad, %d parity classes per workgroup)" % (plan[0], plan[1], plan[2], plan[3], plan[5] - 10, plan[5] - 10)
         elif plan[5] == 7:
-            key = "patch_gemm_x6c_kernel (64 x 256 tile, bf16-split x6)"
-        elif plan[5] == 6:
-            key = "patch_gemm_x6_kernel<%d, %d, %d>%s" % (plan[0], plan[1], plan[2], "" if stride1 else " (strided dgrad classes)")
-        elif not stride1:
-            key = "patch_gemm_dma_kernel(strided dgrad: one launch per parity class)"
-        elif plan[4] < 0:
-            key = "patch_gemm_kernel<%d, %d, %d, %d>" % tuple(plan[:4])
+            key = "patch_gemm_x6c_kernel<%d, %d> (%d x %d tile, bf16-split x6)" % (plan[1] // 32, plan[0] // 32, plan[0], plan[1])
         else:
             key = "patch_gemm_dma_kernel<%d, %d, %d, %d, %d, %d>" % tuple(plan)
     PROFILE.records.append((key, flops, e0, e1))

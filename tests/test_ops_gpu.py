@@ -53,15 +53,17 @@ def _act_cpu(y, act):
     return {"none": lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.2), "tanh": torch.tanh}[act](y)
 
 
-@pytest.fixture(params=["f32", "x6c"])
+@pytest.fixture(params=["f32", "x6c", "x6c81"])
 def engine(request, ops, monkeypatch):
-    """Both convolution engines are held to the same oracle: the f32-MFMA kernels and the bf16-split kernel (conv_x6c.hip).  The
-    latter only takes layers with >= 200 workgroups by default; P2I_X6C_MIN_WG=1 (read per call) sends the small test layers
-    it covers through it too."""
+    """Both convolution engines are held to the same oracle: the f32-MFMA kernels and the bf16-split kernels (conv_x6c.hip).  The
+    latter only take layers with >= 200 workgroups by default; P2I_X6C_MIN_WG=1 (read per call) sends the small test layers
+    they cover through them too, and P2I_X6C_TILE=<waves><channel tiles> pins one tile variant (default: 82 = 64 x 256 where it fills the chip, else 81 = 32 x 256)."""
     old = ops.CONV_ENGINE
     ops.CONV_ENGINE = "f32" if request.param == "f32" else "auto"
-    if request.param == "x6c":
+    if request.param != "f32":
         monkeypatch.setenv("P2I_X6C_MIN_WG", "1")
+        if request.param != "x6c":
+            monkeypatch.setenv("P2I_X6C_TILE", request.param[3:])
     yield request.param
     ops.CONV_ENGINE = old
 
@@ -128,7 +130,8 @@ def test_conv_fwd_dgrad_wgrad(ops, engine, case):
     wp_f, wp_d = ops.weight_pack(w.detach().to(dev))
     xg = x.detach().to(dev)
     yg = ops.conv_fwd(spec, xg, wp_f, bias.detach().to(dev) if has_bias else None, res.to(dev) if has_res else None, act_code)
-    x6c_layer = engine == "x6c" and nd == 2 and k == (3, 3) and st == (1, 1) and name not in ("g3x3_w128", "g3x3_tiny4")    # those two: patch > 384 pixels, f32 engine
+    x6c_layer = engine.startswith("x6c") and nd == 2 and k == (3, 3) and st == (1, 1) and name not in ("g3x3_tiny4", "g3x3_w128", "d2d_to1")
+    # (those three: a 256-position tile spans 16 or 4 images / is 2 x 128 + halo -- patches above the 384-pixel limit, f32 engine)
     if x6c_layer and Cin % 16 == 0:
         assert _last_plan(ops)[5] == 7, (name, _last_plan(ops))
     assert rel_err(yg.cpu().numpy(), out.detach().numpy()) < TOL_OP
