@@ -16,6 +16,16 @@
 
 namespace p2i {
 
+#ifdef P2I_STAMP
+// diagnostic build (tools/build_stamp.sh): per-wave cycle sums of the loop's phases; never defined in the product build
+extern __device__ unsigned long long* p2i_stamp_buf;
+#define X6C_NOW(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define X6C_ACC(sum, t_prev) do { unsigned long long t_; X6C_NOW(t_); sum += t_ - t_prev; t_prev = t_; } while (0)
+#else
+#define X6C_NOW(v) do { } while (0)
+#define X6C_ACC(sum, t_prev) do { } while (0)
+#endif
+
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
 
@@ -93,6 +103,10 @@ __device__ __forceinline__ void x6c_wait_vm(int n) {
 template <int NW, int TM>
 __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef P2I_STAMP
+  unsigned long long st_entry, st_prev, st_wait = 0, st_bar = 0, st_issue = 0, st_mfma = 0, st_loop0;
+  X6C_NOW(st_entry);
+#endif
   constexpr int MB = 32 * TM, NTHR = 64 * NW, NI = X6cTile<NW>::NI;
   constexpr int RING = TM == 2 ? 4 : 6, LEAD = RING - 1;  // a stage is ~1.2 us (TM 2) / ~0.6 us (TM 1) of MFMAs, an L2 -> LDS DMA ~2 us under load
   constexpr int WST = 18 * MB;                            // 16-B elements of one stage's weights: [3 planes][3 taps][2 k-groups][MB m]
@@ -191,20 +205,28 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom
       pb[4 * CSl + it_dst[it]] = lo;
     }
   };
-  // weights of stage (chunk c, kernel row b) -> wbuf[sb]: NWI wave-instructions of 64 x 16 B, dealt round-robin to the waves
+  // weights of stage (chunk c, kernel row b) -> wbuf[sb]: NWI wave-instructions of 64 x 16 B, dealt round-robin to the waves.
+  // The byte offset of instruction r's source at chunk 0 is computed ONCE per kernel row (w_soff[r][b]): inside the loop the
+  // look-up of g.tap_w[] is a scalar load + s_waitcnt lgkmcnt(0) per instruction, 1300-1500 cycles per stage (stamped).
   constexpr int NWR = (NWI + NW - 1) / NW;
+  int w_soff[NWR][3];
+  unsigned w_dst[NWR];
+#pragma unroll
+  for (int r = 0; r < NWR; ++r) {
+    const int u = wave + NW * r;
+    // TM 2: u = (plane, tap, k-group); TM 1: u = (plane, tap), the two k-groups ride in the lane halves
+    const int pt = TM == 2 ? u >> 1 : u, kg = TM == 2 ? u & 1 : 0;
+    const int p = pt / 3, tl = pt % 3;
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      w_soff[r][b] = u < NWI ? __builtin_amdgcn_readfirstlane((((p * g.ntaps_w + g.tap_w[3 * b + tl]) * KCt + kg) * g.CmPad + o0) * 16) : 0;
+    w_dst[r] = wbuf_la + 16u * (unsigned)(u * 64);
+  }
+  const int w_cstep = 2 * g.CmPad * 16;                                // one 16-channel chunk further
   auto issue_w = [&](int c, int b, int sb) {
 #pragma unroll
-    for (int r = 0; r < NWR; ++r) {
-      const int u = wave + NW * r;
-      if (u < NWI) {
-        // TM 2: u = (plane, tap, k-group); TM 1: u = (plane, tap), the two k-groups ride in the lane halves
-        const int pt = TM == 2 ? u >> 1 : u, kg = TM == 2 ? u & 1 : 0;
-        const int p = pt / 3, tl = pt % 3;
-        const int soff = (((p * g.ntaps_w + g.tap_w[3 * b + tl]) * KCt + 2 * c + kg) * g.CmPad + o0) * 16;
-        dma_b128(rs_w, wbuf_la + 16u * (unsigned)(sb * WST + u * 64), wvoff, soff);
-      }
-    }
+    for (int r = 0; r < NWR; ++r)
+      if (wave + NW * r < NWI) dma_b128(rs_w, w_dst[r] + 16u * (unsigned)(sb * WST), wvoff, w_soff[r][b] + c * w_cstep);
   };
 
   const int nch = g.Ck >> 4;
@@ -265,6 +287,9 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom
   };
   const u32x4c* wlane = wbuf + lhi * MB + l31;
   load_tap(wlane, planes + lane_base, 0, 0);
+#ifdef P2I_STAMP
+  X6C_NOW(st_loop0); st_prev = st_loop0;
+#endif
   int s = 0;
   for (int c = 0; c < nch; ++c) {
     const u32x4c* pb = planes + (c & 1) * PST + lane_base;
@@ -280,7 +305,8 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom
         __builtin_amdgcn_sched_barrier(0);
         split_patch(planes + ((c + 1) & 1) * PST);     // buffer read last in chunk c-1
       }
-      if (sa < nst) issue_w(sa / 3, sa % 3, sa % RING);            // slot read last in stage s-1 (complete before its barrier)
+      if (sa < nst) issue_w(c + (b + LEAD) / 3, (b + LEAD) % 3, sa % RING);   // slot read last in stage s-1 (complete before its barrier)
+      X6C_ACC(st_issue, st_prev);                                  // patch loads / split pass / weight DMA issue
       const u32x4c* wsl = wlane + (s % RING) * WST;
       __builtin_amdgcn_sched_barrier(0);
       load_tap(wsl, pb, 3 * b + 1, 1);
@@ -291,6 +317,7 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom
       mfma_tap(1);
       ilv();
       __builtin_amdgcn_sched_barrier(0);
+      X6C_ACC(st_mfma, st_prev);
       // stage s+1 needs its weights W(s+1); everything issued after that batch may stay in flight: W(s+2) .. W(s+LEAD), and the
       // patch loads of the stages s+2-LEAD .. s that start a chunk
       {
@@ -305,13 +332,19 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom
         x6c_wait_vm(n);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // own tap reads and plane writes done
+      X6C_ACC(st_wait, st_prev);
       __builtin_amdgcn_s_barrier();
+      X6C_ACC(st_bar, st_prev);
       if (s + 1 < nst) load_tap(wlane + ((s + 1) % RING) * WST, b == 2 ? pbn : pb, b == 2 ? 0 : 3 * b + 3, 0);
       mfma_tap(2);
       ilv();
       __builtin_amdgcn_sched_barrier(0);
+      X6C_ACC(st_mfma, st_prev);
     }
   }
+#ifdef P2I_STAMP
+  unsigned long long st_loop_end; X6C_NOW(st_loop_end);
+#endif
 
   // ---- epilogue (shared with the f32 engine)
   const int gw = j0w + pjw, gh = j0h + pjh, gb = j0b + pjb;
@@ -321,6 +354,15 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom
 #pragma unroll
   for (int i = 0; i < TM; ++i)
     epilogue_tile16(acc[i], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, g.bias, g.act_epi, g.res, g.mask_y, g.mask_act, g.dst);
+#ifdef P2I_STAMP
+  if (p2i_stamp_buf && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long st_x; X6C_NOW(st_x);
+    unsigned long long* o = p2i_stamp_buf + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * NW + wave) * 8;
+    o[0] = st_wait; o[1] = st_bar; o[2] = st_issue; o[3] = st_mfma; o[4] = st_loop_end - st_loop0; o[5] = st_loop0; o[6] = st_loop0 - st_entry;
+    o[7] = st_x - st_loop_end;
+  }
+#endif
 }
 
 // Fewest workgroups for which a tile variant is used (256 CUs; below that the next smaller tile, or the f32 engine).  Read per call
