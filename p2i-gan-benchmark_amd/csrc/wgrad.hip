@@ -656,6 +656,25 @@ extern "C" int p2i_wgrad_last_plan(int* out4) {
   return P2I_OK;
 }
 
+// dwp[i] += sum over the ns slices of a launch
+static int launch_wgrad_reduce(const float* ws, int ns, long long slice, int Co, int CoPad, float* dwp, hipStream_t s) {
+  const int n4 = (int)(slice / 4);
+  // enough threads to stream the ns * slice floats at HBM rate: split the slices over up to 8 groups while the
+  // columns alone give fewer than ~2 blocks per CU
+  int lsg = 0;
+  while (lsg < 3 && (2 << lsg) <= ns && (n4 >> (8 - lsg)) < 512) ++lsg;
+  const int ncol = 256 >> lsg;
+  const int blocks = (n4 + ncol - 1) / ncol;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, s, ws, ns, slice, n4, Co, CoPad, lsg, dwp);
+  return launch_status();
+}
+
+// wgrad_x6.hip: 3x3 stride-1 2-D layers with 64-multiple channel counts on the bf16 matrix pipe; 1 = not its case
+namespace p2i {
+int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* ws, long long ws_floats, int* ns_out,
+                 long long* slice_out, hipStream_t s);
+}
+
 static thread_local float* g_wgrad_ws = nullptr;          // caller-owned slice scratch of the running p2i_conv_wgrad_ws call
 static thread_local long long g_wgrad_ws_floats = 0;
 
@@ -675,6 +694,17 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
   if (d->Cin == 1 && d->Cout <= 32 && d->kt * d->kh * d->kw <= 32 && !y_act) {
     g_wgrad_plan[0] = 2; g_wgrad_plan[1] = d->kt * d->kh * d->kw; g_wgrad_plan[2] = 0; g_wgrad_plan[3] = 1;
     return c1_wgrad(d, x, dy, dwp, dbias, s);
+  }
+  if (y_act == nullptr && dbias == nullptr) {               // generator DO-Conv layers: bf16-split kernel where it applies
+    int ns6 = 0;
+    long long slice6 = 0;
+    const int rc = run_wgrad_x6(d, x, dy, dwp, g_wgrad_ws, g_wgrad_ws_floats, &ns6, &slice6, s);
+    if (rc != 1) {
+      if (rc) return rc;
+      g_wgrad_plan[0] = 3; g_wgrad_plan[1] = 9; g_wgrad_plan[2] = 1; g_wgrad_plan[3] = 64;
+      if (ns6 >= 2) return launch_wgrad_reduce(g_wgrad_ws, ns6, slice6, d->Cout, (d->Cout + 31) / 32 * 32, dwp, s);
+      return P2I_OK;
+    }
   }
   g_wgrad_plan[0] = 0; g_wgrad_plan[1] = d->kh * d->kw; g_wgrad_plan[2] = 0; g_wgrad_plan[3] = 64;
   WgradGeom g{};
@@ -800,18 +830,8 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
         ga.pstride = slice;
         hipLaunchKernelGGL(kern, dim3(ns, ncb, nco), dim3(512), lds2, s, ga);
         if (int e = launch_status()) return e;
-        if (sliced) {
-          const int n4 = (int)(slice / 4);
-          // enough threads to stream the ns * slice floats at HBM rate: split the slices over up to 8 groups while the
-          // columns alone give fewer than ~2 blocks per CU
-          int lsg = 0;
-          while (lsg < 3 && (2 << lsg) <= ns && (n4 >> (8 - lsg)) < 512) ++lsg;
-          const int ncol = 256 >> lsg;
-          const int blocks = (n4 + ncol - 1) / ncol;
-          hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, s, (const float*)g_wgrad_ws, ns, slice,
-                             n4, d->Cout, g.CoPad, lsg, ga.dwp);
-          if (int e = launch_status()) return e;
-        }
+        if (sliced)
+          if (int e = launch_wgrad_reduce(g_wgrad_ws, ns, slice, d->Cout, g.CoPad, ga.dwp, s)) return e;
       }
     }
   }

@@ -1,0 +1,268 @@
+// Weight gradient of the generator's 3x3 stride-1 DO-Conv layers (2-D, C_in and C_out multiples of 64) on the bf16 matrix pipe with
+// fp32 accuracy: both operands are activations (x and dy), each split exactly into three bf16 terms (hi + mid + lo, truncation
+// split), six v_mfma_f32_32x32x16_bf16 products per fp32 product accumulated in fp32, small terms first (conv_x6c.hip has the
+// numerics; the dropped products are <= 2^-23 |a b|).
+//
+//   dW[tap][c][o] = sum over pixels P of x[c][P + d_tap] * dy[o][P]
+//
+// The contraction runs over PIXELS, so an MFMA operand is "8 consecutive pixels of one channel" -- and a tap moves the x operand by
+// +-1 pixel = 2 bytes, which no aligned 16-byte read of a [channel][pixel] image can follow.  The LDS images are therefore
+// [pixel][64 channels] (a tap shift is a whole ROW of the image) and every operand is fetched with gfx950's transposing read
+// ds_read_b64_tr_b16 (4 pixel rows x 16 channels per 16-lane group, delivered channel-per-lane): two reads per bf16x8 operand.
+//   * workgroup = 64 x-channels x 64 dy-channels x 9 taps over a slice of the pixels (grid.x slices, summed by
+//     wgrad_reduce_kernel exactly like the f32 kernel's slices); 8 waves = 2 tap groups x (2 x 2) channel quadrants: group 0 owns
+//     taps 0-3, group 1 taps 5-8, the centre tap is shared (group 0 takes tile rows 0-1, group 1 rows 2-3, summed through LDS at
+//     the end): 108 MFMAs per wave and tile in both groups, five 32x32 accumulators per wave;
+//   * tile = 4 rows x 16 columns of output pixels (+ halo for x): both tiles go global -> registers -> split -> LDS as bf16 planes
+//     [plane][pixel][64 ch] with a 144-byte pixel pitch (writes conflict-free; transposed reads 2-way on 8 of 64 banks), double
+//     buffered, ONE barrier per tile; no LDS-DMA (nothing here is consumed in its memory layout), so hipcc counts the waits;
+//   * a K-step is one tile row (16 pixels): 6 transposed reads for dy, 6 per tap for x, 54 MFMAs.
+// MFMA-bound time of a 9.1 GFLOP layer: 30.7 us at the 1.8 GHz the chip holds under this load (f32 kernel: 84.5 us measured).
+#include "conv_common.h"
+
+namespace p2i {
+
+typedef short s16x4w __attribute__((ext_vector_type(4)));
+typedef short s16x8w __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+struct Wx6Geom {
+  const float* x;        // (B, Cx, H, W)
+  const float* dy;       // (B, Co, H, W)
+  float* dwp;            // packed grad [9][Cx][CoPad]
+  float* partial;        // != null: slice s stores to partial + s * pstride (same indexing), wgrad_reduce_kernel sums
+  long long pstride;
+  int B, Cx, Co, CoPad, H, W;
+  int nth, ntw, ntiles;
+};
+
+constexpr int WX_TH = 4, WX_TW = 16, WX_EW = WX_TW + 2, WX_EH = WX_TH + 2;
+constexpr int WX_XPX = WX_EH * WX_EW, WX_YPX = WX_TH * WX_TW;          // 108 patch pixels, 64 output pixels
+constexpr int WX_ROW = 144;                                            // bytes per pixel row: 64 ch x 2 B + 16 (36 dwords: 4 * odd)
+constexpr int WX_XPLANE = WX_XPX * WX_ROW, WX_YPLANE = WX_YPX * WX_ROW;
+constexpr int WX_YOFF = 3 * WX_XPLANE, WX_BUF = WX_YOFF + 3 * WX_YPLANE;   // 74 304 B per buffer, two buffers
+constexpr int WX_NXI = (8 * WX_XPX + 511) / 512;                       // x items (pixel, 8-channel chunk) per thread: 2
+
+__device__ __forceinline__ unsigned wx_pack(float lo_elem, float hi_elem) {
+  return (__float_as_uint(lo_elem) >> 16) | (__float_as_uint(hi_elem) & 0xFFFF0000u);
+}
+__device__ __forceinline__ float wx_trunc(float v) { return __uint_as_float(__float_as_uint(v) & 0xFFFF0000u); }
+// exact 3-way truncation split of 8 channel values into three packed bf16x8
+__device__ __forceinline__ void wx_split8(const float (&v)[8], u32x4w& hi, u32x4w& mid, u32x4w& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    hi[j] = wx_pack(a, b);
+    const float ra = a - wx_trunc(a), rb = b - wx_trunc(b);
+    mid[j] = wx_pack(ra, rb);
+    const float sa = ra - wx_trunc(ra), sb = rb - wx_trunc(rb);
+    lo[j] = wx_pack(sa, sb);
+  }
+}
+
+typedef __attribute__((address_space(3))) s16x4w* lds_s16x4_ptr;
+// bf16x8 MFMA operand = 8 consecutive pixels of this lane's channel: two transposed reads of 4 pixel rows each
+__device__ __forceinline__ bf16x8w wx_read_tr(const unsigned char* base, int byte_off) {
+  const s16x4w a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + byte_off));
+  const s16x4w b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + byte_off + 4 * WX_ROW));
+  return __builtin_bit_cast(bf16x8w, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave >> 2, kh = (wave >> 1) & 1, mh = wave & 1;        // tap group, x-channel half, dy-channel half
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1, lhi = lane >> 5, l31 = lane & 31;
+  const int HW = g.H * g.W;
+  const int cb = blockIdx.y, ob = blockIdx.z;
+
+  // ---- staging items of this thread: (patch pixel q, 8-channel chunk); lanes run along q (coalesced loads, conflict-free writes)
+  int x_rel[WX_NXI], x_dst[WX_NXI], x_qr[WX_NXI], x_qc[WX_NXI];
+#pragma unroll
+  for (int it = 0; it < WX_NXI; ++it) {
+    const int e = tid + 512 * it;
+    const bool in = e < 8 * WX_XPX;
+    const int chunk = in ? e / WX_XPX : 0, q = in ? e - chunk * WX_XPX : 0;
+    const int qr = q / WX_EW, qc = q - qr * WX_EW;
+    x_qr[it] = in ? qr - 1 : -(1 << 20);                               // row / column relative to the tile origin; "never valid" when idle
+    x_qc[it] = qc - 1;
+    x_rel[it] = ((cb * 64 + chunk * 8) * g.H + (qr - 1)) * g.W + (qc - 1);
+    x_dst[it] = q * WX_ROW + chunk * 16;
+  }
+  const int y_chunk = tid >> 6, y_q = tid & 63;
+  const int y_rel = ((ob * 64 + y_chunk * 8) * g.H + (y_q >> 4)) * g.W + (y_q & 15);
+  const int y_dst = WX_YOFF + y_q * WX_ROW + y_chunk * 16;
+
+  float xv[WX_NXI][8], yv[8];
+  bool xok[WX_NXI];
+  auto load_tile = [&](int t) {
+    const int tw = t % g.ntw, r0 = t / g.ntw;
+    const int th = r0 % g.nth, b = r0 / g.nth;
+    const int h0 = th * WX_TH, w0 = tw * WX_TW;
+    const int xorg = b * g.Cx * HW + h0 * g.W + w0, yorg = b * g.Co * HW + h0 * g.W + w0;
+#pragma unroll
+    for (int it = 0; it < WX_NXI; ++it) {
+      const int h = h0 + x_qr[it], w = w0 + x_qc[it];
+      xok[it] = (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+      const float* p = g.x + (xok[it] ? xorg + x_rel[it] : 0);          // unconditional loads from a clamped address, masked in split
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv[it][j] = p[(size_t)j * HW];
+    }
+    const float* p = g.dy + yorg + y_rel;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) yv[j] = p[(size_t)j * HW];
+  };
+  auto store_tile = [&](unsigned char* buf) {
+#pragma unroll
+    for (int it = 0; it < WX_NXI; ++it) {
+      if (tid + 512 * it >= 8 * WX_XPX) continue;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = xok[it] ? xv[it][j] : 0.f;
+      u32x4w h, m, l;
+      wx_split8(v, h, m, l);
+      *reinterpret_cast<u32x4w*>(buf + x_dst[it]) = h;
+      *reinterpret_cast<u32x4w*>(buf + WX_XPLANE + x_dst[it]) = m;
+      *reinterpret_cast<u32x4w*>(buf + 2 * WX_XPLANE + x_dst[it]) = l;
+    }
+    u32x4w h, m, l;
+    wx_split8(yv, h, m, l);
+    *reinterpret_cast<u32x4w*>(buf + y_dst) = h;
+    *reinterpret_cast<u32x4w*>(buf + WX_YPLANE + y_dst) = m;
+    *reinterpret_cast<u32x4w*>(buf + 2 * WX_YPLANE + y_dst) = l;
+  };
+
+  // acc[0..3]: this group's own taps (tap = 5 * tg + k); acc[4]: its share of the centre tap
+  f32x16 acc[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposed-read lane bases (bytes inside a buffer): lane 4q+p of a 16-lane group addresses pixel row q, channels 4p .. 4p+3
+  const int a_lane = (8 * lhi + (i16 >> 2)) * WX_ROW + (32 * kh + 16 * g16 + 4 * (i16 & 3)) * 2;
+  const int b_lane = WX_YOFF + (8 * lhi + (i16 >> 2)) * WX_ROW + (32 * mh + 16 * g16 + 4 * (i16 & 3)) * 2;
+  int a_tap[4];                                       // + the tap's pixel shift (dh, dw) -> dh * 18 + dw patch pixels
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int tap = 5 * tg + k;
+    a_tap[k] = a_lane + ((tap / 3) * WX_EW + tap % 3) * WX_ROW;
+  }
+  const int a_ctr = a_lane + (WX_EW + 1) * WX_ROW;
+
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};            // small terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+
+  int t = blockIdx.x;
+  if (t < g.ntiles) {
+    load_tile(t);
+    store_tile(wsm);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (; t < g.ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    const bool more = tn < g.ntiles;
+    if (more) load_tile(tn);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* buf = wsm + cur * WX_BUF;
+#pragma unroll
+    for (int rr = 0; rr < WX_TH; ++rr) {               // a K-step = one tile row = 16 pixels
+      bf16x8w Bv[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) Bv[p] = wx_read_tr(buf + b_lane, p * WX_YPLANE + rr * WX_TW * WX_ROW);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bf16x8w Av[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) Av[p] = wx_read_tr(buf + a_tap[k], p * WX_XPLANE + rr * WX_EW * WX_ROW);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Av[PA[q]], Bv[PB[q]], acc[k], 0, 0, 0);
+      }
+      if ((rr >> 1) == tg) {                           // wave-uniform: the centre tap on this group's half of the tile rows
+        bf16x8w Av[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) Av[p] = wx_read_tr(buf + a_ctr, p * WX_XPLANE + rr * WX_EW * WX_ROW);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Av[PA[q]], Bv[PB[q]], acc[4], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) store_tile(wsm + (cur ^ 1) * WX_BUF);    // buffer read last in the previous tile (all waves are past its barrier)
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- store / accumulate the [tap][c][o] tile.  Own taps go straight out; group 1 parks its share of the centre tap in LDS
+  // (the buffers are free now) and group 0 adds it to its own.
+  f32x4w* red = reinterpret_cast<f32x4w*>(wsm);
+  const int quad = kh * 2 + mh;
+  if (tg == 1) {
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      f32x4w v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[4][4 * j4 + e];
+      red[(quad * 4 + j4) * 64 + lane] = v;
+    }
+  }
+  __syncthreads();
+  if (tg == 0) {
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      const f32x4w v = red[(quad * 4 + j4) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[4][4 * j4 + e] += v[e];
+    }
+  }
+  float* dst = (g.partial ? g.partial + (size_t)blockIdx.x * g.pstride : g.dwp) + ((size_t)cb * 64 + 32 * kh + 4 * lhi) * g.CoPad + ob * 64 + 32 * mh + l31;
+  const size_t tap_stride = (size_t)g.Cx * g.CoPad;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    if (k == 4 && tg == 1) break;
+    float* dt = dst + (k == 4 ? 4 : 5 * tg + k) * tap_stride;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float* o = dt + ((j & 3) + 8 * (j >> 2)) * g.CoPad;
+      if (g.partial) *o = acc[k][j];
+      else atomicAdd(o, acc[k][j]);
+    }
+  }
+}
+
+// 0 = launched (plan filled), 1 = not a case of this kernel (caller continues with the f32 kernels)
+int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* ws, long long ws_floats, int* ns_out,
+                 long long* slice_out, hipStream_t s) {
+  static const int on = getenv("P2I_WGRAD_X6") ? atoi(getenv("P2I_WGRAD_X6")) : 1;
+  if (!on) return 1;
+  if (d->kt != 1 || d->kh != 3 || d->kw != 3 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1 || d->pt != 0) return 1;
+  if (d->Ti != 1 || d->To != 1 || (d->Cin & 63) || (d->Cout & 63) || (d->Wo % WX_TW) || (d->Ho % WX_TH)) return 1;
+  const long long nx = (long long)d->B * d->Cin * d->Hi * d->Wi, ny = (long long)d->B * d->Cout * d->Ho * d->Wo;
+  if (nx >= (1ll << 31) || ny >= (1ll << 31)) return 1;
+  Wx6Geom g{};
+  g.x = x; g.dy = dy; g.dwp = dwp;
+  g.B = d->B; g.Cx = d->Cin; g.Co = d->Cout; g.CoPad = (d->Cout + 31) / 32 * 32; g.H = d->Ho; g.W = d->Wo;
+  g.nth = d->Ho / WX_TH; g.ntw = d->Wo / WX_TW; g.ntiles = d->B * g.nth * g.ntw;
+  const int ncb = d->Cin / 64, nco = d->Cout / 64;
+  int ns = 256 / (ncb * nco);                          // LDS admits one workgroup per CU
+  if (ns < 1) ns = 1;
+  if (ns > g.ntiles) ns = g.ntiles;
+  const long long slice = 9ll * d->Cin * g.CoPad;
+  const bool sliced = ns >= 2 && ws != nullptr && slice * ns <= ws_floats && slice < (1ll << 31);
+  if (ns >= 2 && !sliced) return 1;                    // no scratch for the slices: the f32 kernel's atomic path
+  g.partial = sliced ? ws : nullptr;
+  g.pstride = slice;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_x6_kernel, dim3(ns, ncb, nco), dim3(512), 2 * WX_BUF, s, g);
+  *ns_out = sliced ? ns : 0;
+  *slice_out = slice;
+  return launch_status();
+}
+
+}  // namespace p2i

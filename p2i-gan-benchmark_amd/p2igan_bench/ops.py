@@ -73,7 +73,7 @@ def _prof_end(e0, kind, spec, desc, stride1):
         import ctypes
         wp = (ctypes.c_int * 4)()
         _hip.load().p2i_wgrad_last_plan(wp)
-        key = {0: "wgrad_kernel<64>", 2: "c1_wgrad_kernel<32>"}.get(wp[0]) or \
+        key = {0: "wgrad_kernel<64>", 2: "c1_wgrad_kernel<32>", 3: "wgrad_x6_kernel (bf16-split x6)"}.get(wp[0]) or \
             "wgrad_dma_kernel<64, %d, %s, %d>%s" % (wp[1], "true" if wp[2] else "false", wp[3], "" if spec.k[0] == 1 else " (x%d kt slices)" % spec.k[0])
     else:
         import ctypes

@@ -149,6 +149,11 @@ def test_conv_fwd_dgrad_wgrad(ops, engine, case):
     assert rel_err(dx2.cpu().numpy(), ((x.grad + addt) * (mk > 0)).numpy()) < TOL_OP
     # prologue-free weight gradient on the pre-masked gradient (what the model code uses)
     dwp2, db2 = ops.conv_wgrad(spec, xg, gin.detach().to(dev).contiguous(), want_bias=has_bias)
+    if nd == 2 and k == (3, 3) and st == (1, 1) and Cin % 64 == 0 and Cout % 64 == 0 and sp[0] % 4 == 0 and sp[1] % 16 == 0 and not has_bias:
+        import ctypes
+        wplan = (ctypes.c_int * 4)()
+        ops._hip.load().p2i_wgrad_last_plan(wplan)
+        assert wplan[0] == 3, (name, tuple(wplan))          # the bf16-split weight-gradient kernel (wgrad_x6.hip) took it
     assert rel_err(ops.weight_unpack_grad(dwp2, w.detach().to(dev)).cpu().numpy(), w.grad.numpy()) < TOL_WGRAD
     if has_bias:
         assert rel_err(db2.cpu().numpy(), bias.grad.numpy()) < TOL_WGRAD

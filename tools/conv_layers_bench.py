@@ -59,9 +59,10 @@ for name, spec, (c, t, h, w) in LAYERS:
     dy = torch.randn(ys, device=dev)
     wp_f, wp_d = ops.weight_pack(torch.randn(spec.cout, spec.cin, spec.ntaps, device=dev) * 0.05)
     fl = 2.0 * B * spec.cout * spec.cin * spec.ntaps * to * ho * wo
+    # (the generator's DO-Conv layers have no bias)
     for kind, fn in (("fwd", lambda: ops.conv_fwd(spec, x, wp_f, act=ops.ACT_RELU)),
                      ("dgrad", lambda: ops.conv_dgrad(spec, dy, wp_d, xs, add=x)),
-                     ("wgrad", lambda: ops.conv_wgrad(spec, x, dy, want_bias=True))):
+                     ("wgrad", lambda: ops.conv_wgrad(spec, x, dy, want_bias=not name.startswith("G l")))):
         if which not in ("all", kind):
             continue
         for _ in range(2):
