@@ -95,9 +95,16 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
   const int y_rel = ((ob * 64 + y_chunk * 8) * g.H + (y_q >> 4)) * g.W + (y_q & 15);
   const int y_dst = WX_YOFF + y_q * WX_ROW + y_chunk * 16;
 
-  float xv[WX_NXI][8], yv[8];
+  // The three staging items of a thread (two x items, one dy item; 8 channel values each) live in sv[3][8].  Next tile's 24 loads are
+  // spread over tap-steps 0..7 of the current tile and its split + LDS writes over tap-steps 9..17 (one plane of one item per step),
+  // so that this VALU / VMEM / DS-write work sits in the shadow of the MFMAs instead of between two tiles (15 of 62 us before).
+  float sv[3][8];
   bool xok[WX_NXI];
-  auto load_tile = [&](int t) {
+  const float* sp[3];
+  const bool x1_in = tid + 512 < 8 * WX_XPX;          // this thread has a second x item
+  const int dummy_dst = 2 * WX_BUF + lane * 16;        // LDS slot for the writes of an idle second item (keeps the code branch-free:
+                                                       // the transposed reads interleaved with it need EXEC all ones)
+  auto tile_ptrs = [&](int t) {
     const int tw = t % g.ntw, r0 = t / g.ntw;
     const int th = r0 % g.nth, b = r0 / g.nth;
     const int h0 = th * WX_TH, w0 = tw * WX_TW;
@@ -106,32 +113,31 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
     for (int it = 0; it < WX_NXI; ++it) {
       const int h = h0 + x_qr[it], w = w0 + x_qc[it];
       xok[it] = (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
-      const float* p = g.x + (xok[it] ? xorg + x_rel[it] : 0);          // unconditional loads from a clamped address, masked in split
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xv[it][j] = p[(size_t)j * HW];
+      sp[it] = g.x + (xok[it] ? xorg + x_rel[it] : 0);                  // unconditional loads from a clamped address, masked in split
     }
-    const float* p = g.dy + yorg + y_rel;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) yv[j] = p[(size_t)j * HW];
+    sp[2] = g.dy + yorg + y_rel;
   };
-  auto store_tile = [&](unsigned char* buf) {
+  auto load_chunk = [&](int c) {                        // c = 0..7: loads 3c .. 3c+2 of the 24
 #pragma unroll
-    for (int it = 0; it < WX_NXI; ++it) {
-      if (tid + 512 * it >= 8 * WX_XPX) continue;
-      float v[8];
+    for (int f = 3 * c; f < 3 * c + 3; ++f) sv[f >> 3][f & 7] = sp[f >> 3][(size_t)(f & 7) * HW];
+  };
+  // c = 0..8: plane c % 3 (hi, mid, lo) of item c / 3 -> packed bf16x8 to LDS; the item's values become their own remainder
+  auto split_chunk = [&](int c, unsigned char* buf) {
+    const int it = c / 3, pl = c % 3;
+    float (&v)[8] = sv[it];
+    if (pl == 0 && it < 2) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = xok[it] ? xv[it][j] : 0.f;
-      u32x4w h, m, l;
-      wx_split8(v, h, m, l);
-      *reinterpret_cast<u32x4w*>(buf + x_dst[it]) = h;
-      *reinterpret_cast<u32x4w*>(buf + WX_XPLANE + x_dst[it]) = m;
-      *reinterpret_cast<u32x4w*>(buf + 2 * WX_XPLANE + x_dst[it]) = l;
+      for (int j = 0; j < 8; ++j) v[j] = xok[it] ? v[j] : 0.f;
     }
-    u32x4w h, m, l;
-    wx_split8(yv, h, m, l);
-    *reinterpret_cast<u32x4w*>(buf + y_dst) = h;
-    *reinterpret_cast<u32x4w*>(buf + WX_YPLANE + y_dst) = m;
-    *reinterpret_cast<u32x4w*>(buf + 2 * WX_YPLANE + y_dst) = l;
+    u32x4w w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = wx_pack(v[2 * j], v[2 * j + 1]);
+    const int dst = it == 2 ? y_dst + pl * WX_YPLANE : (it == 1 && !x1_in ? -1 : x_dst[it] + pl * WX_XPLANE);
+    *reinterpret_cast<u32x4w*>(dst < 0 ? wsm + dummy_dst : buf + dst) = w;
+    if (pl < 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] - wx_trunc(v[j]);         // exact
+    }
   };
 
   // acc[0..3]: this group's own taps (tap = 5 * tg + k); acc[4]: its share of the centre tap
@@ -144,53 +150,87 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
   // transposed-read lane bases (bytes inside a buffer): lane 4q+p of a 16-lane group addresses pixel row q, channels 4p .. 4p+3
   const int a_lane = (8 * lhi + (i16 >> 2)) * WX_ROW + (32 * kh + 16 * g16 + 4 * (i16 & 3)) * 2;
   const int b_lane = WX_YOFF + (8 * lhi + (i16 >> 2)) * WX_ROW + (32 * mh + 16 * g16 + 4 * (i16 & 3)) * 2;
-  int a_tap[4];                                       // + the tap's pixel shift (dh, dw) -> dh * 18 + dw patch pixels
+  int a_tap[5];                                       // + the tap's pixel shift (dh, dw) -> dh * 18 + dw patch pixels; [4] = centre
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int tap = 5 * tg + k;
     a_tap[k] = a_lane + ((tap / 3) * WX_EW + tap % 3) * WX_ROW;
   }
-  const int a_ctr = a_lane + (WX_EW + 1) * WX_ROW;
+  a_tap[4] = a_lane + (WX_EW + 1) * WX_ROW;
+  // Both groups run the same static schedule of 18 tap-steps over 4 K-steps (tile rows): K-steps 0 and 1 carry the centre tap too.
+  // Group 1 starts at tile row 2, so "its" centre rows are 2 and 3: row of K-step s = (s + 2 tg) & 3 (a wave-uniform byte offset).
+  int rowx[WX_TH], rowy[WX_TH];
+#pragma unroll
+  for (int ks = 0; ks < WX_TH; ++ks) {
+    const int row = (ks + 2 * tg) & 3;
+    rowx[ks] = row * WX_EW * WX_ROW;
+    rowy[ks] = row * WX_TW * WX_ROW;
+  }
+  constexpr int NSTEP = 18;
+  constexpr int ST_KS[NSTEP] = {0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3};
+  constexpr int ST_K[NSTEP] = {0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 0, 1, 2, 3, 0, 1, 2, 3};
 
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0};            // small terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 
   int t = blockIdx.x;
   if (t < g.ntiles) {
-    load_tile(t);
-    store_tile(wsm);
+    tile_ptrs(t);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) load_chunk(c);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) split_chunk(c, wsm);
   }
   __syncthreads();
   int cur = 0;
   for (; t < g.ntiles; t += gridDim.x) {
     const int tn = t + gridDim.x;
     const bool more = tn < g.ntiles;
-    if (more) load_tile(tn);
-    __builtin_amdgcn_sched_barrier(0);
+    tile_ptrs(more ? tn : t);                          // (the last tile re-stages itself into the idle buffer: branch-free loop body)
     const unsigned char* buf = wsm + cur * WX_BUF;
+    unsigned char* nbuf = wsm + (cur ^ 1) * WX_BUF;    // read last in the previous tile (all waves are past its barrier)
+    // software pipeline over the 18 tap-steps: step i+1's six operand reads (and the next K-step's six dy reads) are issued under
+    // step i's six MFMAs; two register sets each
+    bf16x8w Av[3][3], Bv[2][3];
+    auto load_a = [&](int set, int step) {
+      const unsigned char* p = buf + a_tap[ST_K[step]] + rowx[ST_KS[step]];
 #pragma unroll
-    for (int rr = 0; rr < WX_TH; ++rr) {               // a K-step = one tile row = 16 pixels
-      bf16x8w Bv[3];
+      for (int pl = 0; pl < 3; ++pl) Av[set][pl] = wx_read_tr(p, pl * WX_XPLANE);
+    };
+    auto load_b = [&](int set, int ks) {
+      const unsigned char* p = buf + b_lane + rowy[ks];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) Bv[p] = wx_read_tr(buf + b_lane, p * WX_YPLANE + rr * WX_TW * WX_ROW);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        bf16x8w Av[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) Av[p] = wx_read_tr(buf + a_tap[k], p * WX_XPLANE + rr * WX_EW * WX_ROW);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Av[PA[q]], Bv[PB[q]], acc[k], 0, 0, 0);
-      }
-      if ((rr >> 1) == tg) {                           // wave-uniform: the centre tap on this group's half of the tile rows
-        bf16x8w Av[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) Av[p] = wx_read_tr(buf + a_ctr, p * WX_XPLANE + rr * WX_EW * WX_ROW);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Av[PA[q]], Bv[PB[q]], acc[4], 0, 0, 0);
-      }
-    }
+      for (int pl = 0; pl < 3; ++pl) Bv[set][pl] = wx_read_tr(p, pl * WX_YPLANE);
+    };
+    // x operands are fetched TWO steps ahead (three register sets), dy operands at the first step of the K-step before
+    load_b(0, 0);
+    load_a(0, 0);
+    load_a(1, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) store_tile(wsm + (cur ^ 1) * WX_BUF);    // buffer read last in the previous tile (all waves are past its barrier)
+#pragma unroll
+    for (int i = 0; i < NSTEP; ++i) {
+      const int ks = ST_KS[i], k = ST_K[i];
+      const bool pre_a = i + 2 < NSTEP;
+      const bool pre_b = ks + 1 < WX_TH && (i == 0 || ST_KS[i - 1] != ks);      // first step of a K-step: fetch the next K-step's dy
+      if (i < 8) load_chunk(i);
+      if (i >= 9) split_chunk(i - 9, nbuf);
+      if (pre_a) load_a((i + 2) % 3, i + 2);
+      if (pre_b) load_b((ks + 1) & 1, ks + 1);
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Av[i % 3][PA[q]], Bv[ks & 1][PB[q]], acc[k], 0, 0, 0);
+      // interleave: per MFMA one (two) operand reads and a share of the staging work
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (pre_a && pre_b) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        else if (pre_a || pre_b) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i < 8 && q < 3) { __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        if (i >= 9) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        if (i >= 9 && q == 5) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
     cur ^= 1;
   }
@@ -219,17 +259,17 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
   }
   float* dst = (g.partial ? g.partial + (size_t)blockIdx.x * g.pstride : g.dwp) + ((size_t)cb * 64 + 32 * kh + 4 * lhi) * g.CoPad + ob * 64 + 32 * mh + l31;
   const size_t tap_stride = (size_t)g.Cx * g.CoPad;
+  auto emit = [&](auto&& put) {
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    if (k == 4 && tg == 1) break;
-    float* dt = dst + (k == 4 ? 4 : 5 * tg + k) * tap_stride;
+    for (int k = 0; k < 5; ++k) {
+      if (k == 4 && tg == 1) break;
+      float* dt = dst + (k == 4 ? 4 : 5 * tg + k) * tap_stride;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      float* o = dt + ((j & 3) + 8 * (j >> 2)) * g.CoPad;
-      if (g.partial) *o = acc[k][j];
-      else atomicAdd(o, acc[k][j]);
+      for (int j = 0; j < 16; ++j) put(dt + ((j & 3) + 8 * (j >> 2)) * g.CoPad, acc[k][j]);
     }
-  }
+  };
+  if (g.partial) emit([](float* o, float v) { *o = v; });
+  else emit([](float* o, float v) { atomicAdd(o, v); });
 }
 
 // 0 = launched (plan filled), 1 = not a case of this kernel (caller continues with the f32 kernels)
@@ -259,7 +299,7 @@ int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float*
     (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_x6_kernel, dim3(ns, ncb, nco), dim3(512), 2 * WX_BUF, s, g);
+  hipLaunchKernelGGL(wgrad_x6_kernel, dim3(ns, ncb, nco), dim3(512), 2 * WX_BUF + 1024, s, g);
   *ns_out = sliced ? ns : 0;
   *slice_out = slice;
   return launch_status();
