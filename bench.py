@@ -31,6 +31,7 @@ import torch.distributed as dist  # noqa: E402
 
 T, H, W = 16, 128, 128
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 GFLOP_PER_SAMPLE_STEP = 183.97     # algorithmic conv FLOPs of one full train step
 
 
@@ -304,23 +305,32 @@ def main():
         eng._graph = graph_saved
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the conv-engine instance with the largest share of the step (single-kernel keys only)
-        single = {k: v for k, v in summ.items() if k.startswith(("patch_gemm_dma_kernel<", "wgrad_dma_kernel<")) and "(" not in k}
+        single = {k: v for k, v in summ.items()
+                  if (k.startswith(("patch_gemm_dma_kernel<", "wgrad_dma_kernel<")) and "(" not in k) or k.startswith(("patch_gemm_x6c_kernel<", "wgrad_x6_kernel"))}
         dom = max(single, key=lambda k: single[k]["seconds"])
         d = single[dom]
         ach = d["flops"] / d["seconds"] / 1e12
+        # the bf16-split kernels execute six bf16 MFMA flops per algorithmic (fp32) flop: their bound is the dense bf16 peak / 6
+        x6 = "x6" in dom
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x6 else PEAK_FP32_MFMA_TFLOPS
+        dom_name = dom.split(" (")[0]                  # rocprofv3's kernel name
         # HBM bytes per launch from the committed PMC passes (static: counters cannot be read inside this run).  Corrected as
         # MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 (16-B-per-lane LDS-DMA streams), WRITE_SIZE as read.
         traffic = traffic_src = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             tj = json.load(open(pmc))
-            traffic = tj.get("kernels", tj).get(dom)
+            traffic = tj.get("kernels", tj).get(dom_name)
             traffic_src = tj.get("source")
         note = "instrumented pass: every launch on one stream (P2I_SIDE_WGRAD=0), so a launch's duration is the kernel's own"
-        if dom.startswith("wgrad_dma_kernel") and ops.WGRAD_SLICES:
+        if dom.startswith(("wgrad_dma_kernel", "wgrad_x6_kernel")) and ops.WGRAD_SLICES:
             note += "; HIP events bracket the p2i_conv_wgrad_ws call = this kernel + its wgrad_reduce_kernel (rocprofv3 lists them separately)"
-        roofline = {"bound": "mfma", "kernel": dom, "note": note, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        if x6:
+            note += ("; exact-fp32 result computed as 6 bf16 MFMA products per fp32 product (3-way bf16 split): achieved = algorithmic fp32 flops / time, "
+                     "peak = dense bf16 MFMA peak 2500 / 6; frac_of_f32_mfma_peak prices the same rate against the f32-MFMA peak the f32 kernels are bound by")
+        roofline = {"bound": "mfma", "kernel": dom, "note": note, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "frac_of_f32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_us": round(d["seconds"] / d["launches"] * 1e6, 2),
                     "flops_per_launch": d["flops"] / d["launches"], "launches_per_step": d["launches"] / nprof}
         tot_s = sum(v["seconds"] for v in summ.values())
