@@ -75,7 +75,11 @@ int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, cons
 /* p2i_conv_wgrad with a caller-owned scratch `ws` of ws_floats floats: when it holds every workgroup's partial tile
  * (<= 256 * kh*kw * Cin * pad32(Cout) floats, 37.7 MB for the generator's 3x3 C->C layers) the partial tiles are stored
  * and summed by a second kernel instead of being added with float atomics: faster, and bit-reproducible.  ws == NULL or
- * too small: the atomic path of p2i_conv_wgrad. */
+ * too small: the atomic path of p2i_conv_wgrad.
+ * With a sufficient scratch, 3x3 stride-1 pad-1 2-D layers whose Cin and Cout are multiples of 64, Ho % 4 == 0, Wo % 16 == 0,
+ * called without act'(y) prologue and without dbias (the generator's DO-Conv stack) are computed on the bf16 matrix pipe with fp32
+ * accuracy (wgrad_x6.hip: x and dy split exactly into three bf16 terms each, six MFMA products per fp32 product, transposed
+ * LDS reads); same result contract, same slices + reduce.  P2I_WGRAD_X6=0 keeps the fp32-MFMA kernel. */
 int p2i_conv_wgrad_ws(const p2i_conv_desc* d, const float* x, const float* dy, const float* y_act, int act, float* dwp,
                       float* dbias, float* ws, int64_t ws_floats, void* stream);
 /* Same contracts as p2i_conv_fwd / p2i_conv_dgrad (without the act'(y) prologue).  3x3 stride-1 2-D layers with a contraction
@@ -95,8 +99,8 @@ int p2i_conv_dgrad_x6(const p2i_conv_desc* d, const float* dy, const float* wp_d
  * patch_gemm_kernel<MB,NPIX,WAVES_M,CK>; KG = 7: patch_gemm_x6c_kernel, fields {64,256,1,16,9,7})
  * so that bench.py's roofline can be matched to rocprofv3 rows */
 int p2i_conv_last_plan(int* out6);
-/* same for the most recent p2i_conv_wgrad: {kind (0 wgrad_kernel<64>, 1 wgrad_dma_kernel<64,NTAP,Y4,CB>, 2 c1_wgrad_kernel),
- * NTAP, Y4, CB} */
+/* same for the most recent p2i_conv_wgrad: {kind (0 wgrad_kernel<64>, 1 wgrad_dma_kernel<64,NTAP,Y4,CB>, 2 c1_wgrad_kernel,
+ * 3 wgrad_x6_kernel), NTAP, Y4, CB} */
 int p2i_wgrad_last_plan(int* out4);
 
 /* ------------------------------------------------------------------ weight preparation
