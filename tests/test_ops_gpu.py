@@ -33,6 +33,8 @@ CONV_CASES = [
     ("g3x3_128_s16", 2, 3, 128, 128, (16, 16), (3, 3), (1, 1), (1, 1), "none", False, True),
     ("g3x3_tiny4", 2, 2, 512, 512, (4, 4), (3, 3), (1, 1), (1, 1), "none", False, False),
     ("g3x3_w128", 2, 1, 64, 64, (24, 128), (3, 3), (1, 1), (1, 1), "relu", False, False),
+    ("g3x3_128_multi", 2, 3, 128, 128, (32, 48), (3, 3), (1, 1), (1, 1), "none", False, True),   # wgrad_x6: 72 tiles on 64 slices (1 or 2 per workgroup)
+    ("g3x3_1024_atomic", 2, 1, 1024, 1024, (4, 16), (3, 3), (1, 1), (1, 1), "none", False, False), # 256 channel blocks: one slice, atomic accumulation
     ("g3x3_odd", 2, 3, 32, 48, (19, 21), (3, 3), (1, 1), (1, 1), "relu", True, True),     # partial tiles in H, W and channels
     ("proj1x1", 2, 2, 128, 64, (16, 16), (1, 1), (1, 1), (0, 0), "relu", True, True),
     ("d2d_s2_odd", 2, 2, 16, 32, (20, 22), (3, 3), (2, 2), (1, 1), "leaky", True, False),
@@ -130,7 +132,7 @@ def test_conv_fwd_dgrad_wgrad(ops, engine, case):
     wp_f, wp_d = ops.weight_pack(w.detach().to(dev))
     xg = x.detach().to(dev)
     yg = ops.conv_fwd(spec, xg, wp_f, bias.detach().to(dev) if has_bias else None, res.to(dev) if has_res else None, act_code)
-    x6c_layer = engine.startswith("x6c") and nd == 2 and k == (3, 3) and st == (1, 1) and name not in ("g3x3_tiny4", "g3x3_w128", "d2d_to1")
+    x6c_layer = engine.startswith("x6c") and nd == 2 and k == (3, 3) and st == (1, 1) and name not in ("g3x3_tiny4", "g3x3_w128", "d2d_to1", "g3x3_1024_atomic")
     # (those three: a 256-position tile spans 16 or 4 images / is 2 x 128 + halo -- patches above the 384-pixel limit, f32 engine)
     if x6c_layer and Cin % 16 == 0:
         assert _last_plan(ops)[5] == 7, (name, _last_plan(ops))
