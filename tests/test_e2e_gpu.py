@@ -156,13 +156,26 @@ def _hip_full_step(dev, golden, name, h):
     return eng, (frames, masked, masks)
 
 
-def test_full_size_train_step_128_matches_reference_golden(dev, golden):
+@pytest.fixture(params=["auto", "f32"])
+def engines(request, monkeypatch):
+    """Both sets of convolution kernels are held to the reference's full-size goldens: "auto" = the default (bf16-split x6c forward /
+    dgrad and wgrad_x6 weight gradient where they apply, f32-MFMA kernels elsewhere), "f32" = f32-MFMA kernels only."""
+    from p2igan_bench import ops
+    old = ops.CONV_ENGINE
+    ops.CONV_ENGINE = request.param
+    if request.param == "f32":
+        monkeypatch.setenv("P2I_WGRAD_X6", "0")
+    yield request.param
+    ops.CONV_ENGINE = old
+
+
+def test_full_size_train_step_128_matches_reference_golden(dev, golden, engines):
     """configs[1] geometry (B=2 of the B=8 workload; 128x128; 79-gauge 'stis' mask and an 'sti' block-10 mask): forward,
     backward through D and G, wgrad (256-slice path), spectral-norm gradient, Adam -- vs e2e_128.npz."""
     _hip_full_step(dev, golden, "e2e_128.npz", 128)
 
 
-def test_full_size_train_step_256_matches_reference_golden(dev, golden):
+def test_full_size_train_step_256_matches_reference_golden(dev, golden, engines):
     """configs[3] geometry (256x256, 316 gauges): the re-sized tiles through a whole train step -- vs e2e_256.npz."""
     _hip_full_step(dev, golden, "e2e_256.npz", 256)
 
