@@ -94,6 +94,17 @@ int p2i_conv_fwd_x6(const p2i_conv_desc* d, const float* x, const float* wp, uin
                     const float* residual, float* y, int act, void* stream);
 int p2i_conv_dgrad_x6(const p2i_conv_desc* d, const float* dy, const float* wp_d, uint16_t* wsplit, const float* dx_add,
                       const float* mask_y, int mask_act, float* dx, void* stream);
+/* Pre-split variant: split a weight tensor -- or a whole stack of same-shape packed tensors [n][ntaps][K][pad32(M)], passed as
+ * ntaps = n * taps -- ONCE per weight update (p2i_x6_split; wb: 3 * ntaps * K * Mpad uint16, image Wb[plane][ntaps][K/8][Mpad][8]),
+ * then call p2i_conv_fwd_x6s / p2i_conv_dgrad_x6s any number of times with wb_layer = wb + layer * taps * K * Mpad (uint16 elements:
+ * plane 0 of that layer) and ntaps_w = the stack's total tap count.  p2i_x6c_would_take tells (1 / 0) whether a call with this
+ * geometry would use the split at all, so that callers can skip splitting stacks no layer needs. */
+int p2i_x6_split(const float* wp, uint16_t* wb, int ntaps, int K, int Mpad, void* stream);
+int p2i_x6c_would_take(const p2i_conv_desc* d, int dgrad);
+int p2i_conv_fwd_x6s(const p2i_conv_desc* d, const float* x, const float* wp, const uint16_t* wb_layer, int ntaps_w,
+                     const float* bias, const float* residual, float* y, int act, void* stream);
+int p2i_conv_dgrad_x6s(const p2i_conv_desc* d, const float* dy, const float* wp_d, const uint16_t* wb_layer, int ntaps_w,
+                       const float* dx_add, const float* mask_y, int mask_act, float* dx, void* stream);
 /* tile plan {MB, NPIX, WAVES_M, CK, NT, KG} of the calling thread's most recent fwd/dgrad launch: names the
  * patch_gemm_dma_kernel<MB,NPIX,WAVES_M,CK,NT,KG> instance (NT = -1: the prologue kernel
  * patch_gemm_kernel<MB,NPIX,WAVES_M,CK>; KG = 7: patch_gemm_x6c_kernel, fields {64,256,1,16,9,7})

@@ -557,3 +557,39 @@ extern "C" int p2i_conv_dgrad_x6(const p2i_conv_desc* d, const float* dy, const 
   x6_ctx() = X6Ctx{nullptr, 0};
   return rc;
 }
+
+// ---- pre-split weights: split once per weight update (a whole stack of same-shape packed tensors in one launch), then any number
+// of conv calls.  `wb_layer` points at plane 0 of THIS layer inside the stack's split image Wb[plane][ntaps_w][K/8][pad32(M)][8].
+extern "C" int p2i_x6_split(const float* wp, uint16_t* wb, int ntaps, int K, int Mpad, void* stream) {
+  P2I_REQUIRE(wp && wb && ntaps > 0 && K > 0 && (K & 7) == 0 && Mpad > 0 && (Mpad & 31) == 0, "p2i_x6_split: bad arguments");
+  return x6_split_weights(wp, wb, ntaps, K, Mpad, (hipStream_t)stream);
+}
+
+extern "C" int p2i_x6c_would_take(const p2i_conv_desc* d, int dgrad) {
+  if (check_desc(d)) return 0;
+  if (dgrad ? ((d->Cout & 15) != 0 || d->Cin == 1) : (d->Cin & 15) != 0) return 0;
+  return x6c_would_take(d, dgrad != 0) ? 1 : 0;
+}
+
+extern "C" int p2i_conv_fwd_x6s(const p2i_conv_desc* d, const float* x, const float* wp, const uint16_t* wb_layer, int ntaps_w,
+                                const float* bias, const float* residual, float* y, int act, void* stream) {
+  if (int e = check_desc(d)) return e;
+  if (wb_layer == nullptr || (d->Cin & 15) != 0 || !x6c_would_take(d, false)) return p2i_conv_fwd(d, x, wp, bias, residual, y, act, stream);
+  P2I_REQUIRE(ntaps_w >= d->kt * d->kh * d->kw, "ntaps_w smaller than the layer's tap count");
+  x6_ctx() = X6Ctx{wb_layer, ntaps_w};
+  const int rc = p2i_conv_fwd(d, x, wp, bias, residual, y, act, stream);
+  x6_ctx() = X6Ctx{nullptr, 0};
+  return rc;
+}
+
+extern "C" int p2i_conv_dgrad_x6s(const p2i_conv_desc* d, const float* dy, const float* wp_d, const uint16_t* wb_layer, int ntaps_w,
+                                  const float* dx_add, const float* mask_y, int mask_act, float* dx, void* stream) {
+  if (int e = check_desc(d)) return e;
+  if (wb_layer == nullptr || (d->Cout & 15) != 0 || d->Cin == 1 || !x6c_would_take(d, true))
+    return p2i_conv_dgrad(d, dy, nullptr, P2I_ACT_NONE, wp_d, dx_add, mask_y, mask_act, dx, stream);
+  P2I_REQUIRE(ntaps_w >= d->kt * d->kh * d->kw, "ntaps_w smaller than the layer's tap count");
+  x6_ctx() = X6Ctx{wb_layer, ntaps_w};
+  const int rc = p2i_conv_dgrad(d, dy, nullptr, P2I_ACT_NONE, wp_d, dx_add, mask_y, mask_act, dx, stream);
+  x6_ctx() = X6Ctx{nullptr, 0};
+  return rc;
+}

@@ -449,7 +449,7 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   if (sbytes >= 0x7FFFFFF0ull) return 1;
   g.mg_ew = magic_u16(g.eW); g.mg_eh = magic_u16(g.eH);
   g.wb = wb; g.ntaps_w = ntaps_w;
-  g.wb_bytes = 3u * (unsigned)ntaps_w * (unsigned)g.Ck * (unsigned)g.CmPad * 2u;
+  g.wb_bytes = (2u * (unsigned)ntaps_w + 9u) * (unsigned)g.Ck * (unsigned)g.CmPad * 2u;   // planes 0..2 of this layer inside a stack of ntaps_w taps
   g.nclass = 1;
   const int ring = tv.TM == 2 ? 4 : 6;
   const size_t lds = sizeof(float) * (size_t)((g.CSl + 3) & ~3) + 16 * (size_t)(ring * 18 * 32 * tv.TM + 2 * 6 * g.CSl);

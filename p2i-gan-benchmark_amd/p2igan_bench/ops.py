@@ -112,6 +112,40 @@ def _x6_scratch(numel: int, device):
     return buf
 
 
+class X6Stack:
+    """bf16 split of a stack of same-shape packed weights (n, taps, K, Mpad), made ONCE per weight update and on first need: the
+    conv calls of its n layers then skip their per-call split (60 launches of ~5 us per step before).  Attached to the packed
+    tensors as `wp._x6s = (stack, layer index)` by the batched fold / pack helpers."""
+
+    def __init__(self, wstack):
+        self.w = wstack
+        self.wb = None
+        self.n, self.taps, self.k, self.mpad = wstack.shape
+
+    def layer_ptr(self, i):
+        if self.wb is None:                 # first layer that the bf16-split kernel takes: split the whole stack in one launch
+            self.wb = torch.empty(3 * self.w.numel(), device=self.w.device, dtype=torch.int16)
+            _hip.check(_hip.load().p2i_x6_split(_ptr(self.w), _ptr(self.wb), self.n * self.taps, self.k, self.mpad, _stream()), "p2i_x6_split")
+        return self.wb.data_ptr() + 2 * i * self.taps * self.k * self.mpad
+
+    @staticmethod
+    def attach(wstack, views):
+        """views[i] is the caller's view wstack[i] (the attribute lives on the view OBJECT that is handed to the conv calls)."""
+        if CONV_ENGINE in ("auto", "x6") and wstack is not None and wstack.shape[2] % 16 == 0 and wstack.shape[3] % 32 == 0:
+            st = X6Stack(wstack)
+            for i, v in enumerate(views):
+                v._x6s = (st, i)
+
+
+def _x6s_of(wp, d, dgrad):
+    """(layer pointer, total taps) of a pre-split stack when this call would run on the bf16-split kernel, else None."""
+    h = getattr(wp, "_x6s", None)
+    if h is None or CONV_ENGINE not in ("auto", "x6") or not _hip.load().p2i_x6c_would_take(d, 1 if dgrad else 0):
+        return None
+    st, i = h
+    return st.layer_ptr(i), st.n * st.taps
+
+
 # Weight-gradient partial tiles: stored to a per-stream scratch and summed by a second kernel (deterministic, and faster than
 # 256-way float atomics); P2I_WGRAD_SLICES=0 keeps the atomic path.  256 slices * 9 taps * 64 * 64 floats cover every layer.
 WGRAD_SLICES = _os.environ.get("P2I_WGRAD_SLICES", "1") != "0"
@@ -214,8 +248,12 @@ def conv_fwd(spec: ConvSpec, x, wp_f, bias=None, residual=None, act=ACT_NONE, ou
     _chk(x, wp_f, bias, residual, y)
     d = spec.desc(b, t, h, w)
     e0 = _prof_begin()
-    ws = _x6_scratch(3 * wp_f.numel(), x.device) if spec.cin % 16 == 0 else None
-    if ws is not None:
+    pre = _x6s_of(wp_f, d, False)
+    ws = _x6_scratch(3 * wp_f.numel(), x.device) if (pre is None and spec.cin % 16 == 0) else None
+    if pre is not None:
+        _hip.check(lib.p2i_conv_fwd_x6s(d, _ptr(x), _ptr(wp_f), pre[0], pre[1], _ptr(bias), _ptr(residual), _ptr(y), act, _stream()),
+                   "p2i_conv_fwd_x6s")
+    elif ws is not None:
         _hip.check(lib.p2i_conv_fwd_x6(d, _ptr(x), _ptr(wp_f), _ptr(ws), _ptr(bias), _ptr(residual), _ptr(y), act, _stream()),
                    "p2i_conv_fwd_x6")
     else:
@@ -246,8 +284,12 @@ def conv_dgrad(spec: ConvSpec, dy, wp_d, in_shape, y_act=None, act=ACT_NONE, add
     _chk(dy, wp_d, y_act, dx, add, mask_y)
     d = spec.desc(b, t, h, w)
     e0 = _prof_begin()
-    ws = _x6_scratch(3 * wp_d.numel(), dy.device) if (y_act is None and spec.cout % 16 == 0 and spec.cin > 1) else None
-    if ws is not None:
+    pre = _x6s_of(wp_d, d, True) if y_act is None else None
+    ws = _x6_scratch(3 * wp_d.numel(), dy.device) if (pre is None and y_act is None and spec.cout % 16 == 0 and spec.cin > 1) else None
+    if pre is not None:
+        _hip.check(lib.p2i_conv_dgrad_x6s(d, _ptr(dy), _ptr(wp_d), pre[0], pre[1], _ptr(add), _ptr(mask_y), mask_act, _ptr(dx), _stream()),
+                   "p2i_conv_dgrad_x6s")
+    elif ws is not None:
         _hip.check(lib.p2i_conv_dgrad_x6(d, _ptr(dy), _ptr(wp_d), _ptr(ws), _ptr(add), _ptr(mask_y), mask_act, _ptr(dx), _stream()),
                    "p2i_conv_dgrad_x6")
     else:
@@ -376,7 +418,12 @@ def doconv_fold_batched(layers, out_ch, in_ch, need_d=True):
                                                _ptr_array([l[2] for l in layers]), n, out_ch, in_ch, _ptr_array([wf[i] for i in range(n)]),
                                                _ptr_array([wd[i] for i in range(n)]) if need_d else None, _stream()),
                "p2i_doconv_fold_fwd_batched")
-    return [(wf[i], wd[i] if need_d else None) for i in range(n)]
+    wfs = [wf[i] for i in range(n)]
+    wds = [wd[i] for i in range(n)] if need_d else [None] * n
+    X6Stack.attach(wf, wfs)
+    if need_d:
+        X6Stack.attach(wd, wds)
+    return list(zip(wfs, wds))
 
 
 def doconv_fold_bwd_batched(dwps, layers, out_ch, in_ch, outs=None):

@@ -108,6 +108,34 @@ def test_x6c_engine_is_used(ops, monkeypatch):
         ops.CONV_ENGINE = old
 
 
+def test_x6c_presplit_stack_matches_per_call_split(ops, monkeypatch):
+    """Weights split ONCE per stack (ops.X6Stack, p2i_x6_split + p2i_conv_*_x6s) give bit-identical results to the per-call split,
+    for every layer of the stack, forward and data gradient."""
+    monkeypatch.setenv("P2I_X6C_MIN_WG", "1")
+    old = ops.CONV_ENGINE
+    try:
+        ops.CONV_ENGINE = "auto"
+        spec = ops.ConvSpec(64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+        n = 3
+        wf = torch.stack([ops.weight_pack(_rand(64, 64, 9, seed=10 + i, scale=0.05).cuda())[0] for i in range(n)])
+        wd = torch.stack([ops.weight_pack(_rand(64, 64, 9, seed=10 + i, scale=0.05).cuda())[1] for i in range(n)])
+        x = _rand(2, 64, 32, 32, seed=3).cuda()
+        plain = [(ops.conv_fwd(spec, x, wf[i].contiguous()), ops.conv_dgrad(spec, x, wd[i].contiguous(), tuple(x.shape))) for i in range(n)]
+        assert _last_plan(ops)[5] == 7
+        wfs, wds = [wf[i] for i in range(n)], [wd[i] for i in range(n)]
+        ops.X6Stack.attach(wf, wfs)
+        ops.X6Stack.attach(wd, wds)
+        for i in (2, 0, 1):                                   # any order: the stack is split at the first layer that needs it
+            y = ops.conv_fwd(spec, x, wfs[i])
+            assert _last_plan(ops)[5] == 7
+            dx = ops.conv_dgrad(spec, x, wds[i], tuple(x.shape))
+            assert _last_plan(ops)[5] == 7
+            assert torch.equal(y, plain[i][0]) and torch.equal(dx, plain[i][1])
+        assert wfs[0]._x6s[0].wb is not None and wfs[0]._x6s[0] is wfs[2]._x6s[0]
+    finally:
+        ops.CONV_ENGINE = old
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(ops, engine, case):
     name, nd, B, Cin, Cout, sp, k, st, pd, act, has_bias, has_res = case
