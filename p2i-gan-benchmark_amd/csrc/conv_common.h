@@ -91,6 +91,47 @@ __device__ __forceinline__ void epilogue_tile16(const f32x16& acc, int o_base, i
   }
 }
 
+// Epilogue of TWO accumulator tiles whose destinations interleave along w (input-parity classes (.., pW=0) and (.., pW=1) of a
+// stride-2 data gradient, destination row pitch even): element r of both tiles belongs to the same lane and to adjacent
+// addresses, so residual / mask are fetched and the result is stored as float2 -- full 128-B lines per 16 lanes instead of two
+// half-used ones per class (WRITE_SIZE of the fused strided dgrad was 1.6x its algorithmic bytes).  pos_off: class pW=0, even.
+__device__ __forceinline__ void epilogue_pair16(const f32x16& acc0, const f32x16& acc1, int o_base, int lhi, int Cm, bool pv, size_t pos_off,
+                                                size_t chan_stride, const float* __restrict__ res, const float* __restrict__ mask_y,
+                                                int mask_act, float* __restrict__ dst) {
+  typedef float f32x2e __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int h8 = 0; h8 < 2; ++h8) {
+    int di[8];
+    bool ok[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = h8 * 8 + k;
+      const int o = o_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      ok[k] = pv && o < Cm;
+      di[k] = ok[k] ? (int)((size_t)o * chan_stride + pos_off) : 0;
+    }
+    f32x2e rv[8], mv[8];
+    if (res) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) rv[k] = *reinterpret_cast<const f32x2e*>(res + di[k]);
+    }
+    if (mask_y) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) mv[k] = *reinterpret_cast<const f32x2e*>(mask_y + di[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = h8 * 8 + k;
+      f32x2e v;
+      v[0] = acc0[r]; v[1] = acc1[r];
+      if (res) { v[0] += rv[k][0]; v[1] += rv[k][1]; }
+      if (mask_y) { v[0] = act_grad(v[0], mv[k][0], mask_act); v[1] = act_grad(v[1], mv[k][1], mask_act); }
+      if (ok[k]) *reinterpret_cast<f32x2e*>(dst + di[k]) = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 static inline void pick_tile_dims(int NPIX, int B, int nT, int nH, int nW, int& jb, int& jt, int& jh, int& jw) {
   jw = pow2_ceil(nW); if (jw > 32) jw = 32;
   int rem = NPIX / jw;
@@ -167,6 +208,7 @@ struct PatchGeom {
   unsigned wb_bytes;
   int ntaps_w;          // taps of the full kernel (plane stride of wb)
   int TG, NTP, R;       // taps per pipeline stage; padded tap count of the LDS weight-offset table; weight ring slots
+  int pair_w;           // fused strided dgrad: classes 2k / 2k+1 interleave along w and are stored together as float2
   int nclass;           // > 1: fields below override nT..ntaps / tap tables per blockIdx.z
   ClassGeom cls[MAX_CLASSES];
 };

@@ -238,6 +238,30 @@ __global__ __launch_bounds__(256) void patch_gemm_fused_kernel(const PatchGeom g
   }
 
   const int dHW = g.dH * g.dW;
+  // classes are ordered (pT, pH, pW) with pW fastest (conv.hip): q = 2k, 2k+1 differ in pW only.  With an even destination row they
+  // cover the same (t, h, w/2) grid and interleave along w: stored together as float2 (g.pair_w, set by the host).
+  if (NCLS == 4 && g.pair_w) {
+#pragma unroll
+    for (int q = 0; q < NCLS; q += 2) {
+      const ClassGeom& cg = g.cls[q];
+      const int c_nT = cg.nT, c_nH = cg.nH, c_nW = cg.nW, c_pT = cg.pT, c_pH = cg.pH, c_pW = cg.pW;
+#pragma unroll
+      for (int f = 0; f < TN; ++f) {
+        const int pix = (wn * TN + f) * 32 + l31;
+        const int gw = j0w + (pix & JWm);
+        const int gh = j0h + ((pix >> g.ljw) & JHm);
+        const int gt = j0t + ((pix >> (g.ljw + g.ljh)) & JTm);
+        const int gb = j0b + (pix >> (g.ljw + g.ljh + g.ljt));
+        const bool pv = gb < g.B && gt < c_nT && gh < c_nH && gw < c_nW;
+        const int sp = (gt * g.oT + c_pT) * dHW + (gh * g.oH + c_pH) * g.dW + gw * g.oW + c_pW;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          epilogue_pair16(acc[q][i][f], acc[q + 1][i][f], o0 + (wm * TM + i) * 32, lhi, g.Cm, pv, (size_t)gb * g.Cm * g.dT * dHW + sp,
+                          (size_t)g.dT * dHW, g.res, g.mask_y, g.mask_act, g.dst);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < NCLS; ++q) {
     const ClassGeom& cg = g.cls[q];
@@ -296,6 +320,16 @@ int run_patch_gemm_fused(PatchGeom g, const ClassSpec* css, int ncls, int* plan6
     ntt += cs.ntaps;
   }
   if (mx[0] <= 0 || mx[1] <= 0 || mx[2] <= 0 || ntt == 0 || ntt > MAX_TAPS) return 1;
+  {
+    // float2 epilogue: classes (2k, 2k+1) = (.., pW 0), (.., pW 1) over the same grid, even destination row, 8-byte aligned tensors
+    static const int pair_on = getenv("P2I_DGRAD_PAIR") ? atoi(getenv("P2I_DGRAD_PAIR")) : 1;
+    bool pair = pair_on && c0s.oW == 2 && (g.dW & 1) == 0;
+    for (int q = 0; q < ncls && pair; q += 2)
+      pair = css[q].pW == 0 && css[q + 1].pW == 1 && css[q].pT == css[q + 1].pT && css[q].pH == css[q + 1].pH &&
+             css[q].nT == css[q + 1].nT && css[q].nH == css[q + 1].nH && css[q].nW == css[q + 1].nW;
+    const unsigned long long al = (unsigned long long)g.dst | (unsigned long long)g.res | (unsigned long long)g.mask_y;
+    g.pair_w = (pair && (al & 7ull) == 0) ? 1 : 0;
+  }
   g.mT = g.mH = g.mW = 1;
   g.oT = c0s.oT; g.oH = c0s.oH; g.oW = c0s.oW;
   // 64-channel m-tiles unless that leaves half of the CUs without a workgroup (deep, small layers)
