@@ -29,8 +29,9 @@ extern __device__ unsigned long long* p2i_stamp_buf;
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
 
+// (lo_elem >> 16) | (hi_elem & 0xFFFF0000) in one v_perm_b32: bytes {lo.2, lo.3, hi.2, hi.3}
 __device__ __forceinline__ unsigned pack_hi16c(float lo_elem, float hi_elem) {
-  return (__float_as_uint(lo_elem) >> 16) | (__float_as_uint(hi_elem) & 0xFFFF0000u);
+  return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
 }
 __device__ __forceinline__ float trunc_bf16c(float v) { return __uint_as_float(__float_as_uint(v) & 0xFFFF0000u); }
 __device__ __forceinline__ void split8c(const float (&v)[8], u32x4c& hi, u32x4c& mid, u32x4c& lo) {

@@ -36,6 +36,7 @@ struct Wx6Geom {
   long long pstride;
   int B, Cx, Co, CoPad, H, W;
   int nth, ntw, ntiles;
+  unsigned x_bytes, dy_bytes;
 };
 
 constexpr int WX_TH = 4, WX_TW = 16, WX_EW = WX_TW + 2, WX_EH = WX_TH + 2;
@@ -45,8 +46,9 @@ constexpr int WX_XPLANE = WX_XPX * WX_ROW, WX_YPLANE = WX_YPX * WX_ROW;
 constexpr int WX_YOFF = 3 * WX_XPLANE, WX_BUF = WX_YOFF + 3 * WX_YPLANE;   // 74 304 B per buffer, two buffers
 constexpr int WX_NXI = (8 * WX_XPX + 511) / 512;                       // x items (pixel, 8-channel chunk) per thread: 2
 
+// (lo_elem >> 16) | (hi_elem & 0xFFFF0000) in one v_perm_b32: bytes {lo.2, lo.3, hi.2, hi.3}
 __device__ __forceinline__ unsigned wx_pack(float lo_elem, float hi_elem) {
-  return (__float_as_uint(lo_elem) >> 16) | (__float_as_uint(hi_elem) & 0xFFFF0000u);
+  return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
 }
 __device__ __forceinline__ float wx_trunc(float v) { return __uint_as_float(__float_as_uint(v) & 0xFFFF0000u); }
 // exact 3-way truncation split of 8 channel values into three packed bf16x8
@@ -99,8 +101,12 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
   // spread over tap-steps 0..7 of the current tile and its split + LDS writes over tap-steps 9..17 (one plane of one item per step),
   // so that this VALU / VMEM / DS-write work sits in the shadow of the MFMAs instead of between two tiles (15 of 62 us before).
   float sv[3][8];
-  bool xok[WX_NXI];
-  const float* sp[3];
+  // Loads go through buffer descriptors: a pixel of the halo that lies outside the image gets an out-of-range offset and comes back
+  // as 0 from the hardware range check (no per-element select, no 64-bit address arithmetic: the channel stride rides in the
+  // scalar offset).  so[3]: byte offset of the item's first channel, or 0xFFFFFF00 when the pixel is outside.
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, (int)g.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dy), 0, (int)g.dy_bytes, 0x00020000);
+  unsigned so[3];
   const bool x1_in = tid + 512 < 8 * WX_XPX;          // this thread has a second x item
   const int dummy_dst = 2 * WX_BUF + lane * 16;        // LDS slot for the writes of an idle second item (keeps the code branch-free:
                                                        // the transposed reads interleaved with it need EXEC all ones)
@@ -112,23 +118,21 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
 #pragma unroll
     for (int it = 0; it < WX_NXI; ++it) {
       const int h = h0 + x_qr[it], w = w0 + x_qc[it];
-      xok[it] = (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
-      sp[it] = g.x + (xok[it] ? xorg + x_rel[it] : 0);                  // unconditional loads from a clamped address, masked in split
+      const bool ok = (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+      so[it] = ok ? 4u * (unsigned)(xorg + x_rel[it]) : 0xFFFFFF00u;
     }
-    sp[2] = g.dy + yorg + y_rel;
+    so[2] = 4u * (unsigned)(yorg + y_rel);
   };
+  const int chan_bytes = 4 * HW;
   auto load_chunk = [&](int c) {                        // c = 0..7: loads 3c .. 3c+2 of the 24
 #pragma unroll
-    for (int f = 3 * c; f < 3 * c + 3; ++f) sv[f >> 3][f & 7] = sp[f >> 3][(size_t)(f & 7) * HW];
+    for (int f = 3 * c; f < 3 * c + 3; ++f)
+      sv[f >> 3][f & 7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((f >> 3) == 2 ? rs_y : rs_x, so[f >> 3], (f & 7) * chan_bytes, 0));
   };
   // c = 0..8: plane c % 3 (hi, mid, lo) of item c / 3 -> packed bf16x8 to LDS; the item's values become their own remainder
   auto split_chunk = [&](int c, unsigned char* buf) {
     const int it = c / 3, pl = c % 3;
     float (&v)[8] = sv[it];
-    if (pl == 0 && it < 2) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = xok[it] ? v[j] : 0.f;
-    }
     u32x4w w;
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = wx_pack(v[2 * j], v[2 * j + 1]);
@@ -279,10 +283,11 @@ int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float*
   if (d->kt != 1 || d->kh != 3 || d->kw != 3 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1 || d->pt != 0) return 1;
   if (d->Ti != 1 || d->To != 1 || (d->Cin & 63) || (d->Cout & 63) || (d->Wo % WX_TW) || (d->Ho % WX_TH)) return 1;
   const long long nx = (long long)d->B * d->Cin * d->Hi * d->Wi, ny = (long long)d->B * d->Cout * d->Ho * d->Wo;
-  if (nx >= (1ll << 31) || ny >= (1ll << 31)) return 1;
+  if (nx >= (1ll << 30) - 64 || ny >= (1ll << 30) - 64) return 1;        // byte offsets in 32 bits, below the out-of-range marker
   Wx6Geom g{};
   g.x = x; g.dy = dy; g.dwp = dwp;
   g.B = d->B; g.Cx = d->Cin; g.Co = d->Cout; g.CoPad = (d->Cout + 31) / 32 * 32; g.H = d->Ho; g.W = d->Wo;
+  g.x_bytes = (unsigned)(4 * nx); g.dy_bytes = (unsigned)(4 * ny);
   g.nth = d->Ho / WX_TH; g.ntw = d->Wo / WX_TW; g.ntiles = d->B * g.nth * g.ntw;
   const int ncb = d->Cin / 64, nco = d->Cout / 64;
   int ns = 256 / (ncb * nco);                          // LDS admits one workgroup per CU
