@@ -99,29 +99,30 @@ __device__ __forceinline__ void epilogue_pair16(const f32x16& acc0, const f32x16
                                                 size_t chan_stride, const float* __restrict__ res, const float* __restrict__ mask_y,
                                                 int mask_act, float* __restrict__ dst) {
   typedef float f32x2e __attribute__((ext_vector_type(2)));
+  // batches of 4 (8 floats in flight per tensor): the <32,128,1,*,4> instances must stay below 256 VGPRs to keep two workgroups per CU
 #pragma unroll
-  for (int h8 = 0; h8 < 2; ++h8) {
-    int di[8];
-    bool ok[8];
+  for (int h4 = 0; h4 < 4; ++h4) {
+    int di[4];
+    bool ok[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int r = h8 * 8 + k;
+    for (int k = 0; k < 4; ++k) {
+      const int r = h4 * 4 + k;
       const int o = o_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
       ok[k] = pv && o < Cm;
       di[k] = ok[k] ? (int)((size_t)o * chan_stride + pos_off) : 0;
     }
-    f32x2e rv[8], mv[8];
+    f32x2e rv[4], mv[4];
     if (res) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) rv[k] = *reinterpret_cast<const f32x2e*>(res + di[k]);
+      for (int k = 0; k < 4; ++k) rv[k] = *reinterpret_cast<const f32x2e*>(res + di[k]);
     }
     if (mask_y) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) mv[k] = *reinterpret_cast<const f32x2e*>(mask_y + di[k]);
+      for (int k = 0; k < 4; ++k) mv[k] = *reinterpret_cast<const f32x2e*>(mask_y + di[k]);
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int r = h8 * 8 + k;
+    for (int k = 0; k < 4; ++k) {
+      const int r = h4 * 4 + k;
       f32x2e v;
       v[0] = acc0[r]; v[1] = acc1[r];
       if (res) { v[0] += rv[k][0]; v[1] += rv[k][1]; }
