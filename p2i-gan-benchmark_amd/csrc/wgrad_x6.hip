@@ -14,16 +14,17 @@
 //     taps 0-3, group 1 taps 5-8, the centre tap is shared (group 0 takes tile rows 0-1, group 1 rows 2-3, summed through LDS at
 //     the end): 108 MFMAs per wave and tile in both groups, five 32x32 accumulators per wave;
 //   * tile = 4 rows x 16 columns of output pixels (+ halo for x): both tiles go global -> registers -> split -> LDS as bf16 planes
-//     [plane][pixel][64 ch] with a 144-byte pixel pitch (writes conflict-free; transposed reads 2-way on 8 of 64 banks), double
+//     [plane][pixel][64 ch] with a 144-byte pixel pitch (writes conflict-free; transposed reads 2-way on 16 of 64 banks), double
 //     buffered, ONE barrier per tile; no LDS-DMA (nothing here is consumed in its memory layout), so hipcc counts the waits;
-//   * a K-step is one tile row (16 pixels): 6 transposed reads for dy, 6 per tap for x, 54 MFMAs.
-// MFMA-bound time of a 9.1 GFLOP layer: 30.7 us at the 1.8 GHz the chip holds under this load (f32 kernel: 84.5 us measured).
+//   * a K-step is one tile row (16 pixels): 6 transposed reads for dy, 6 per tap for x, 24-30 MFMAs per wave; both tap groups run
+//     one static schedule of 18 tap-steps per tile with the operand reads two steps ahead and the next tile's staging (24 buffer
+//     loads with hardware zero for the halo, 9 split + ds_write_b128 chunks) spread over the steps.
+// MFMA-bound time of a 9.1 GFLOP layer: 30.7 us at the 1.8 GHz the chip holds under this load; measured 49 us (f32 kernel: 84.5 us).
 #include "conv_common.h"
 
 namespace p2i {
 
 typedef short s16x4w __attribute__((ext_vector_type(4)));
-typedef short s16x8w __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 typedef float f32x4w __attribute__((ext_vector_type(4)));
