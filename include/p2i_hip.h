@@ -98,9 +98,11 @@ int p2i_conv_dgrad_x6(const p2i_conv_desc* d, const float* dy, const float* wp_d
  * ntaps = n * taps -- ONCE per weight update (p2i_x6_split; wb: 3 * ntaps * K * Mpad uint16, image Wb[plane][ntaps][K/8][Mpad][8]),
  * then call p2i_conv_fwd_x6s / p2i_conv_dgrad_x6s any number of times with wb_layer = wb + layer * taps * K * Mpad (uint16 elements:
  * plane 0 of that layer) and ntaps_w = the stack's total tap count.  p2i_x6c_would_take tells (1 / 0) whether a call with this
- * geometry would use the split at all, so that callers can skip splitting stacks no layer needs. */
+ * geometry (and, for a forward call, this epilogue activation) would use the split at all, so that callers can skip splitting
+ * stacks no layer needs.  Layers with too few output tiles for 256 CUs whose epilogue is linear (no activation) run with the channel
+ * chunks split over two workgroups per tile that add their partial sums into the zeroed destination (P2I_X6C_KSPLIT=0 disables). */
 int p2i_x6_split(const float* wp, uint16_t* wb, int ntaps, int K, int Mpad, void* stream);
-int p2i_x6c_would_take(const p2i_conv_desc* d, int dgrad);
+int p2i_x6c_would_take(const p2i_conv_desc* d, int dgrad, int act);
 int p2i_conv_fwd_x6s(const p2i_conv_desc* d, const float* x, const float* wp, const uint16_t* wb_layer, int ntaps_w,
                      const float* bias, const float* residual, float* y, int act, void* stream);
 int p2i_conv_dgrad_x6s(const p2i_conv_desc* d, const float* dy, const float* wp_d, const uint16_t* wb_layer, int ntaps_w,

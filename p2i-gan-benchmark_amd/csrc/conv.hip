@@ -533,7 +533,7 @@ namespace p2i { int x6_split_weights(const float* wp, uint16_t* wb, int ntaps, i
 extern "C" int p2i_conv_fwd_x6(const p2i_conv_desc* d, const float* x, const float* wp, uint16_t* wsplit, const float* bias,
                                const float* residual, float* y, int act, void* stream) {
   if (int e = check_desc(d)) return e;
-  if (wsplit == nullptr || (d->Cin & 15) != 0 || !x6c_would_take(d, false))
+  if (wsplit == nullptr || (d->Cin & 15) != 0 || !x6c_would_take(d, false, act))
     return p2i_conv_fwd(d, x, wp, bias, residual, y, act, stream);
   P2I_REQUIRE(wp != nullptr, "null pointer");
   const int nt = d->kt * d->kh * d->kw;
@@ -547,7 +547,7 @@ extern "C" int p2i_conv_fwd_x6(const p2i_conv_desc* d, const float* x, const flo
 extern "C" int p2i_conv_dgrad_x6(const p2i_conv_desc* d, const float* dy, const float* wp_d, uint16_t* wsplit, const float* dx_add,
                                  const float* mask_y, int mask_act, float* dx, void* stream) {
   if (int e = check_desc(d)) return e;
-  if (wsplit == nullptr || (d->Cout & 15) != 0 || d->Cin == 1 || !x6c_would_take(d, true))
+  if (wsplit == nullptr || (d->Cout & 15) != 0 || d->Cin == 1 || !x6c_would_take(d, true, P2I_ACT_NONE))
     return p2i_conv_dgrad(d, dy, nullptr, P2I_ACT_NONE, wp_d, dx_add, mask_y, mask_act, dx, stream);
   P2I_REQUIRE(wp_d != nullptr, "null pointer");
   const int nt = d->kt * d->kh * d->kw;
@@ -565,16 +565,16 @@ extern "C" int p2i_x6_split(const float* wp, uint16_t* wb, int ntaps, int K, int
   return x6_split_weights(wp, wb, ntaps, K, Mpad, (hipStream_t)stream);
 }
 
-extern "C" int p2i_x6c_would_take(const p2i_conv_desc* d, int dgrad) {
+extern "C" int p2i_x6c_would_take(const p2i_conv_desc* d, int dgrad, int act) {
   if (check_desc(d)) return 0;
   if (dgrad ? ((d->Cout & 15) != 0 || d->Cin == 1) : (d->Cin & 15) != 0) return 0;
-  return x6c_would_take(d, dgrad != 0) ? 1 : 0;
+  return x6c_would_take(d, dgrad != 0, dgrad ? P2I_ACT_NONE : act) ? 1 : 0;
 }
 
 extern "C" int p2i_conv_fwd_x6s(const p2i_conv_desc* d, const float* x, const float* wp, const uint16_t* wb_layer, int ntaps_w,
                                 const float* bias, const float* residual, float* y, int act, void* stream) {
   if (int e = check_desc(d)) return e;
-  if (wb_layer == nullptr || (d->Cin & 15) != 0 || !x6c_would_take(d, false)) return p2i_conv_fwd(d, x, wp, bias, residual, y, act, stream);
+  if (wb_layer == nullptr || (d->Cin & 15) != 0 || !x6c_would_take(d, false, act)) return p2i_conv_fwd(d, x, wp, bias, residual, y, act, stream);
   P2I_REQUIRE(ntaps_w >= d->kt * d->kh * d->kw, "ntaps_w smaller than the layer's tap count");
   x6_ctx() = X6Ctx{wb_layer, ntaps_w};
   const int rc = p2i_conv_fwd(d, x, wp, bias, residual, y, act, stream);
@@ -585,7 +585,7 @@ extern "C" int p2i_conv_fwd_x6s(const p2i_conv_desc* d, const float* x, const fl
 extern "C" int p2i_conv_dgrad_x6s(const p2i_conv_desc* d, const float* dy, const float* wp_d, const uint16_t* wb_layer, int ntaps_w,
                                   const float* dx_add, const float* mask_y, int mask_act, float* dx, void* stream) {
   if (int e = check_desc(d)) return e;
-  if (wb_layer == nullptr || (d->Cout & 15) != 0 || d->Cin == 1 || !x6c_would_take(d, true))
+  if (wb_layer == nullptr || (d->Cout & 15) != 0 || d->Cin == 1 || !x6c_would_take(d, true, P2I_ACT_NONE))
     return p2i_conv_dgrad(d, dy, nullptr, P2I_ACT_NONE, wp_d, dx_add, mask_y, mask_act, dx, stream);
   P2I_REQUIRE(ntaps_w >= d->kt * d->kh * d->kw, "ntaps_w smaller than the layer's tap count");
   x6_ctx() = X6Ctx{wb_layer, ntaps_w};

@@ -53,7 +53,9 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 // cycles per workgroup on the generator's dgrad launches (a quarter of the kernel).
 __device__ __forceinline__ void epilogue_tile16(const f32x16& acc, int o_base, int lhi, int Cm, bool pv, size_t pos_off, size_t chan_stride,
                                                 const float* __restrict__ bias, int act_epi, const float* __restrict__ res,
-                                                const float* __restrict__ mask_y, int mask_act, float* __restrict__ dst) {
+                                                const float* __restrict__ mask_y, int mask_act, float* __restrict__ dst,
+                                                bool atomic_out = false) {
+  // atomic_out: the value is ADDED to a pre-zeroed destination (split-K partial sums; every term of the epilogue must be linear)
   // two batches of 8 with 32-bit element offsets (tensors are < 2^31 elements: check_desc) and a scheduling fence per batch: without
   // the fence hipcc hoists the loads of EVERY tile of the workgroup to the top and the register allocation grows by ~100
 #pragma unroll
@@ -85,7 +87,10 @@ __device__ __forceinline__ void epilogue_tile16(const f32x16& acc, int o_base, i
       v = act_apply(v, act_epi);
       if (res) v += rv[k];
       if (mask_y) v = act_grad(v, mv[k], mask_act);
-      if (ok[k]) dst[di[k]] = v;
+      if (ok[k]) {
+        if (atomic_out) atomicAdd(dst + di[k], v);
+        else dst[di[k]] = v;
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -209,6 +214,7 @@ struct PatchGeom {
   unsigned wb_bytes;
   int ntaps_w;          // taps of the full kernel (plane stride of wb)
   int TG, NTP, R;       // taps per pipeline stage; padded tap count of the LDS weight-offset table; weight ring slots
+  int ksplit;           // x6c: > 1 = blockIdx.z takes 1/ksplit of the channel chunks and ADDS its partial sums to a zeroed dst
   int pair_w;           // fused strided dgrad: classes 2k / 2k+1 interleave along w and are stored together as float2
   int nclass;           // > 1: fields below override nT..ntaps / tap tables per blockIdx.z
   ClassGeom cls[MAX_CLASSES];
@@ -231,7 +237,7 @@ X6Ctx& x6_ctx();
 
 // 3x3 stride-1 2-D layers on the bf16 matrix pipe, chunk/tap-row pipeline (conv_x6c.hip); returns 1 when it does not apply
 int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s);
-bool x6c_would_take(const p2i_conv_desc* d, bool dgrad);
+bool x6c_would_take(const p2i_conv_desc* d, bool dgrad, int act_epi);
 
 // strided dgrad with the parity classes fused in one workgroup (conv_fused.hip); returns 1 when it does not apply
 int run_patch_gemm_fused(PatchGeom g, const ClassSpec* css, int ncls, int* plan6, hipStream_t s);

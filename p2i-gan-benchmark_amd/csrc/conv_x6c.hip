@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom
   const int sHW = g.sH * g.sW;
   const int src_h0 = j0h + g.bH, src_w0 = j0w + g.bW;
   const int KCt = g.Ck >> 3;
+  const int c0 = blockIdx.z * ((g.Ck >> 4) / g.ksplit);   // split-K: first channel chunk of this workgroup
 
   for (int e = tid; e < CSl; e += NTHR) {
     const int row = fast_div(e, g.mg_ew);
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom
 #pragma unroll
   for (int it = 0; it < NI; ++it) it_voff[it] = (it_off[it] < 0 ? 0 : it_off[it]) * 4;
   auto load_patch = [&](int c) {
-    const float* sc = g.src + (size_t)c * 16 * sHW;
+    const float* sc = g.src + (size_t)(c0 + c) * 16 * sHW;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const float* sq = sc + (size_t)q * sHW;
@@ -227,10 +228,10 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom
   auto issue_w = [&](int c, int b, int sb) {
 #pragma unroll
     for (int r = 0; r < NWR; ++r)
-      if (wave + NW * r < NWI) dma_b128(rs_w, w_dst[r] + 16u * (unsigned)(sb * WST), wvoff, w_soff[r][b] + c * w_cstep);
+      if (wave + NW * r < NWI) dma_b128(rs_w, w_dst[r] + 16u * (unsigned)(sb * WST), wvoff, w_soff[r][b] + (c0 + c) * w_cstep);
   };
 
-  const int nch = g.Ck >> 4;
+  const int nch = (g.Ck >> 4) / g.ksplit;             // this workgroup's chunks: [c0, c0 + nch)
   const int nst = 3 * nch;
   const int nw_mine = (NWI / NW) + (wave < NWI % NW ? 1 : 0);          // this wave's DMA instructions per weight batch
   constexpr int NPL = 8 * NI;                                           // patch loads per thread and chunk
@@ -354,7 +355,11 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom
   const size_t pos = (size_t)gb * g.Cm * dHW + (size_t)gh * g.dW + gw;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
-    epilogue_tile16(acc[i], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, g.bias, g.act_epi, g.res, g.mask_y, g.mask_act, g.dst);
+    if (g.ksplit > 1)       // partial sum: bias / residual ride with split 0, the mask factor (0/1 for relu') distributes over the sum
+      epilogue_tile16(acc[i], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, blockIdx.z ? nullptr : g.bias, P2I_ACT_NONE,
+                      blockIdx.z ? nullptr : g.res, g.mask_y, g.mask_act, g.dst, true);
+    else
+      epilogue_tile16(acc[i], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, g.bias, g.act_epi, g.res, g.mask_y, g.mask_act, g.dst);
 #ifdef P2I_STAMP
   if (p2i_stamp_buf && lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -376,31 +381,54 @@ struct X6cVariant { int NW, TM; };
 static const X6cVariant kX6cVariants[] = {{8, 2}, {8, 1}};      // in order of per-CU efficiency
 constexpr int kNX6cVariants = 2;
 
-struct X6cPick { int v, jb, jh, jw, csl; long long wgs; };
-// first variant whose grid fills the chip and whose patch fits; v = -1: none
-static X6cPick x6c_pick(int B, int nH, int nW, int Cm) {
+struct X6cPick { int v, jb, jh, jw, csl, ksplit; long long wgs; };
+// first variant whose grid fills the chip and whose patch fits; v = -1: none.  When even the 32 x 256 tiles are too few (the
+// 512-channel level at B = 8: 128 tiles) and the epilogue is linear (no activation: split partial sums cannot pass through one),
+// the channel chunks are split over two workgroups per tile that add into a zeroed destination (two addends: order-independent).
+static X6cPick x6c_pick(int B, int nH, int nW, int Cm, int Ck, bool linear_epi) {
   const int forced = x6c_forced(), min_wg = x6c_min_wg();
-  for (int v = 0; v < kNX6cVariants; ++v) {
-    const X6cVariant& t = kX6cVariants[v];
-    if (forced && forced != t.NW * 10 + t.TM) continue;
-    int jb, jt, jh, jw;
-    pick_tile_dims(32 * t.NW, B, 1, nH, nW, jb, jt, jh, jw);
-    const int csl = jb * (jh + 2) * (jw + 2);
-    if (jt != 1 || csl > (t.NW == 8 ? X6cTile<8>::MAXCSL : X6cTile<4>::MAXCSL)) continue;
-    const long long wgs = (long long)ceil_div(B, jb) * ceil_div(nH, jh) * ceil_div(nW, jw) * ceil_div(Cm, 32 * t.TM);
-    if (wgs >= min_wg) return X6cPick{v, jb, jh, jw, csl, wgs};
-  }
-  return X6cPick{-1, 0, 0, 0, 0, 0};
+  static const int ksplit_on = getenv("P2I_X6C_KSPLIT") ? atoi(getenv("P2I_X6C_KSPLIT")) : 1;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int v = 0; v < kNX6cVariants; ++v) {
+      const X6cVariant& t = kX6cVariants[v];
+      if (forced && forced != t.NW * 10 + t.TM) continue;
+      if (pass == 1 && (t.TM != 1 || !ksplit_on || !linear_epi || ((Ck >> 4) & 1) || forced)) continue;
+      int jb, jt, jh, jw;
+      pick_tile_dims(32 * t.NW, B, 1, nH, nW, jb, jt, jh, jw);
+      const int csl = jb * (jh + 2) * (jw + 2);
+      if (jt != 1 || csl > (t.NW == 8 ? X6cTile<8>::MAXCSL : X6cTile<4>::MAXCSL)) continue;
+      const long long wgs = (long long)ceil_div(B, jb) * ceil_div(nH, jh) * ceil_div(nW, jw) * ceil_div(Cm, 32 * t.TM) * (pass + 1);
+      if (wgs >= min_wg) return X6cPick{v, jb, jh, jw, csl, pass + 1, wgs};
+    }
+  return X6cPick{-1, 0, 0, 0, 0, 1, 0};
 }
 
 // cheap host-side test used before the weights are split: would run_patch_gemm_x6c take this layer?
-bool x6c_would_take(const p2i_conv_desc* d, bool dgrad) {
+bool x6c_would_take(const p2i_conv_desc* d, bool dgrad, int act_epi) {
   static const int on = getenv("P2I_CONV_X6C") ? atoi(getenv("P2I_CONV_X6C")) : 1;
   if (!on || d->kt != 1 || d->kh != 3 || d->kw != 3 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->Ti != 1 || d->To != 1) return false;
   const int Ck = dgrad ? d->Cout : d->Cin, Cm = dgrad ? d->Cin : d->Cout;
   const int nH = dgrad ? d->Hi : d->Ho, nW = dgrad ? d->Wi : d->Wo;
   if ((Ck & 15) != 0 || Ck < 16) return false;
-  return x6c_pick(d->B, nH, nW, Cm).v >= 0;
+  (void)act_epi;                                       // (an activation is applied by a second pass when the launch is split-K)
+  return x6c_pick(d->B, nH, nW, Cm, Ck, true).v >= 0;
+}
+
+// second pass of a split-K forward whose epilogue has an activation: y = act(sum of the two partial sums [+ bias, added by split 0])
+// + residual, in place (4 MB at the 512-channel level: ~3 us)
+__global__ __launch_bounds__(256) void x6c_post_act_kernel(float* __restrict__ y, const float* __restrict__ res, long long n4, int act) {
+  typedef float f32x4p __attribute__((ext_vector_type(4)));
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    f32x4p v = reinterpret_cast<f32x4p*>(y)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act);
+    if (res) {
+      const f32x4p r = reinterpret_cast<const f32x4p*>(res)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += r[e];
+    }
+    reinterpret_cast<f32x4p*>(y)[i] = v;
+  }
 }
 
 template <int NW, int TM>
@@ -428,7 +456,8 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
     }
   }
   if (lo[0] != 0 || hi[0] != 0 || hi[1] - lo[1] != 2 || hi[2] - lo[2] != 2) return 1;
-  const X6cPick pk = x6c_pick(g.B, cs.nH, cs.nW, g.Cm);
+  const long long n_dst = (long long)g.B * g.Cm * g.dT * g.dH * g.dW;
+  const X6cPick pk = x6c_pick(g.B, cs.nH, cs.nW, g.Cm, g.Ck, (n_dst & 3) == 0);
   if (pk.v < 0) return 1;
   const X6cVariant& tv = kX6cVariants[pk.v];
   const int jb = pk.jb, jh = pk.jh, jw = pk.jw;
@@ -445,7 +474,8 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   g.ntaps = 9;
   g.nth = ceil_div(cs.nH, jh); g.ntw = ceil_div(cs.nW, jw); g.ntt = 1;
   const int ntb = ceil_div(g.B, jb);
-  const dim3 grid((unsigned)(ntb * g.nth * g.ntw), (unsigned)ceil_div(g.Cm, 32 * tv.TM));
+  g.ksplit = pk.ksplit;
+  const dim3 grid((unsigned)(ntb * g.nth * g.ntw), (unsigned)ceil_div(g.Cm, 32 * tv.TM), (unsigned)pk.ksplit);
   const unsigned long long sbytes = 4ull * g.B * g.Ck * g.sH * g.sW;
   if (sbytes >= 0x7FFFFFF0ull) return 1;
   g.mg_ew = magic_u16(g.eW); g.mg_eh = magic_u16(g.eH);
@@ -454,9 +484,20 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   g.nclass = 1;
   const int ring = tv.TM == 2 ? 4 : 6;
   const size_t lds = sizeof(float) * (size_t)((g.CSl + 3) & ~3) + 16 * (size_t)(ring * 18 * 32 * tv.TM + 2 * 6 * g.CSl);
-  if (plan6) { plan6[0] = 32 * tv.TM; plan6[1] = 32 * tv.NW; plan6[2] = 1; plan6[3] = 16; plan6[4] = 9; plan6[5] = 7; }
+  const int post_act = (pk.ksplit > 1 && g.act_epi != P2I_ACT_NONE) ? g.act_epi : P2I_ACT_NONE;
+  const float* post_res = nullptr;
+  if (pk.ksplit > 1) {       // partial sums are added: start from zero (stream-ordered in front of the kernel)
+    if (hipMemsetAsync(g.dst, 0, sizeof(float) * (size_t)n_dst, s) != hipSuccess) return P2I_EINVAL;
+    if (post_act != P2I_ACT_NONE) { post_res = g.res; g.res = nullptr; g.act_epi = P2I_ACT_NONE; }   // act(sum + bias) + res: second pass
+  }
+  if (plan6) { plan6[0] = 32 * tv.TM; plan6[1] = 32 * tv.NW; plan6[2] = pk.ksplit; plan6[3] = 16; plan6[4] = 9; plan6[5] = 7; }
   if (tv.TM == 2) x6c_launch<8, 2>(g, grid, lds, s);
   else x6c_launch<8, 1>(g, grid, lds, s);
+  if (post_act != P2I_ACT_NONE) {
+    const long long n4 = n_dst / 4;
+    const long long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(x6c_post_act_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, g.dst, post_res, n4, post_act);
+  }
   return launch_status();
 }
 

@@ -137,10 +137,10 @@ class X6Stack:
                 v._x6s = (st, i)
 
 
-def _x6s_of(wp, d, dgrad):
+def _x6s_of(wp, d, dgrad, act=ACT_NONE):
     """(layer pointer, total taps) of a pre-split stack when this call would run on the bf16-split kernel, else None."""
     h = getattr(wp, "_x6s", None)
-    if h is None or CONV_ENGINE not in ("auto", "x6") or not _hip.load().p2i_x6c_would_take(d, 1 if dgrad else 0):
+    if h is None or CONV_ENGINE not in ("auto", "x6") or not _hip.load().p2i_x6c_would_take(d, 1 if dgrad else 0, act):
         return None
     st, i = h
     return st.layer_ptr(i), st.n * st.taps
@@ -248,7 +248,7 @@ def conv_fwd(spec: ConvSpec, x, wp_f, bias=None, residual=None, act=ACT_NONE, ou
     _chk(x, wp_f, bias, residual, y)
     d = spec.desc(b, t, h, w)
     e0 = _prof_begin()
-    pre = _x6s_of(wp_f, d, False)
+    pre = _x6s_of(wp_f, d, False, act)
     ws = _x6_scratch(3 * wp_f.numel(), x.device) if (pre is None and spec.cin % 16 == 0) else None
     if pre is not None:
         _hip.check(lib.p2i_conv_fwd_x6s(d, _ptr(x), _ptr(wp_f), pre[0], pre[1], _ptr(bias), _ptr(residual), _ptr(y), act, _stream()),

@@ -108,6 +108,38 @@ def test_x6c_engine_is_used(ops, monkeypatch):
         ops.CONV_ENGINE = old
 
 
+def test_x6c_split_k_matches_f32_engine(ops, monkeypatch):
+    """Layers with too few tiles for the chip and a linear epilogue run with the channel chunks split over two workgroups per tile
+    that ADD into the zeroed destination (plan[2] == 2): bias / residual ride with split 0, the relu' mask distributes over the sum.
+    Two addends => the result does not depend on the order.  A forward with an activation gets it (and the residual, which comes
+    after the activation) from a second in-place pass."""
+    old = ops.CONV_ENGINE
+    try:
+        spec = ops.ConvSpec(64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+        wp_f, wp_d = ops.weight_pack(_rand(64, 64, 9, seed=21, scale=0.05).cuda())
+        x = _rand(2, 64, 32, 32, seed=22).cuda()          # 32 x 256 tiles: 8 x 2 = 16 workgroups
+        res, bias, mk = _rand(2, 64, 32, 32, seed=23).cuda(), _rand(64, seed=24).cuda(), _rand(2, 64, 32, 32, seed=25).cuda()
+        ops.CONV_ENGINE = "f32"
+        y32 = ops.conv_fwd(spec, x, wp_f, bias=bias, residual=res)
+        dx32 = ops.conv_dgrad(spec, x, wp_d, tuple(x.shape), add=res, mask_y=mk, mask_act=ops.ACT_RELU)
+        ops.CONV_ENGINE = "auto"
+        monkeypatch.setenv("P2I_X6C_MIN_WG", "17")        # 16 < 17 <= 32: only the split-K launch fills "the chip"
+        y = ops.conv_fwd(spec, x, wp_f, bias=bias, residual=res)
+        assert _last_plan(ops)[5] == 7 and _last_plan(ops)[2] == 2, _last_plan(ops)
+        y_again = ops.conv_fwd(spec, x, wp_f, bias=bias, residual=res)
+        dx = ops.conv_dgrad(spec, x, wp_d, tuple(x.shape), add=res, mask_y=mk, mask_act=ops.ACT_RELU)
+        assert _last_plan(ops)[5] == 7 and _last_plan(ops)[2] == 2, _last_plan(ops)
+        assert rel_err(y.cpu().numpy(), y32.cpu().numpy()) < 5e-6 and rel_err(dx.cpu().numpy(), dx32.cpu().numpy()) < 5e-6
+        assert torch.equal(y, y_again)                    # run-to-run reproducible
+        ya = ops.conv_fwd(spec, x, wp_f, bias=bias, residual=res, act=ops.ACT_RELU)       # activation: applied by a second pass
+        assert _last_plan(ops)[5] == 7 and _last_plan(ops)[2] == 2, _last_plan(ops)
+        ops.CONV_ENGINE = "f32"
+        ya32 = ops.conv_fwd(spec, x, wp_f, bias=bias, residual=res, act=ops.ACT_RELU)
+        assert rel_err(ya.cpu().numpy(), ya32.cpu().numpy()) < 5e-6
+    finally:
+        ops.CONV_ENGINE = old
+
+
 def test_x6c_presplit_stack_matches_per_call_split(ops, monkeypatch):
     """Weights split ONCE per stack (ops.X6Stack, p2i_x6_split + p2i_conv_*_x6s) give bit-identical results to the per-call split,
     for every layer of the stack, forward and data gradient."""
