@@ -38,91 +38,117 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   for (int t = 0; t < T; ++t) out[((size_t)b * T + t) * HW + p] = h[t];
 }
 
-template <int T>
-__device__ __forceinline__ void attn_bwd_pixel(const float* __restrict__ x, const float* __restrict__ dout, float (&sw)[2][T * T + T],
-                                               float (&sg)[2][T * T + T], int b, int p, int HW);
+// parameter gradients only (the block's input is data).  Pixels whose dout is all zero (every non-gauge pixel: the IDW scatter
+// touches gauge voxels only) are skipped.  A pixel's contribution is two rank-1 updates (dg ⊗ h, T x T each) + two bias rows.
+// The first version let each active LANE add its 2 (T*T + T) products into LDS with atomics: one lane, ~550 dependent LDS
+// atomics, 122 us per launch with ~1 active pixel per block.  Now the active pixels of a block are listed in LDS (their four
+// T-vectors) in rounds of ATTN_LIST entries and EVERY thread owns parameter elements and sums over the list: no LDS atomics, a fixed
+// summation order inside the block; one global atomic per parameter and block at the end (blocks without an active pixel skip it).
+constexpr int ATTN_LIST = 32;
 
-// parameter gradients only (the block's input is data).  Pixels whose dout is all zero (every
-// non-gauge pixel: the IDW scatter touches gauge voxels only) are skipped.
 template <int T>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                        const float* __restrict__ b0, const float* __restrict__ w1,
                                                        const float* __restrict__ b1, const float* __restrict__ dout,
                                                        float* dw0, float* db0, float* dw1, float* db1, int B, int HW) {
-  __shared__ float sw[2][T * T + T];
-  __shared__ float sg[2][T * T + T];
+  constexpr int NP = T * T + T;                        // parameters per layer: weight rows then bias
+  constexpr int NE = (2 * NP + 255) / 256;             // parameter elements per thread
+  __shared__ float sw[2][NP];
+  __shared__ float lst[ATTN_LIST][4][T];               // per listed pixel: dg1, h0, dg2, h1
+  __shared__ int wave_cnt[4];
   for (int i = threadIdx.x; i < T * T; i += blockDim.x) { sw[0][i] = w0[i]; sw[1][i] = w1[i]; }
   for (int i = threadIdx.x; i < T; i += blockDim.x) { sw[0][T * T + i] = b0[i]; sw[1][T * T + i] = b1[i]; }
-  for (int i = threadIdx.x; i < 2 * (T * T + T); i += blockDim.x) (&sg[0][0])[i] = 0.f;
-  __syncthreads();
   const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  attn_bwd_pixel<T>(x, dout, sw, sg, b, p, HW);
-  __syncthreads();
-  for (int i = threadIdx.x; i < T * T + T; i += blockDim.x) {
-    const float v0 = sg[0][i], v1 = sg[1][i];
-    if (v0 != 0.f) atomicAdd((i < T * T ? dw0 + i : db0 + (i - T * T)), v0);
-    if (v1 != 0.f) atomicAdd((i < T * T ? dw1 + i : db1 + (i - T * T)), v1);
-  }
-}
-
-template <int T>
-__device__ __forceinline__ void attn_bwd_pixel(const float* __restrict__ x, const float* __restrict__ dout, float (&sw)[2][T * T + T],
-                                               float (&sg)[2][T * T + T], int b, int p, int HW) {
-  if (p >= HW) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float go[T];
   bool any = false;
+  if (p < HW) {
 #pragma unroll
-  for (int t = 0; t < T; ++t) { go[t] = dout[((size_t)b * T + t) * HW + p]; any |= (go[t] != 0.f); }
-  if (!any) return;
-  float h0[T], g1[T], a1[T], h1[T], g2[T], a2[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) h0[t] = x[((size_t)b * T + t) * HW + p];
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    float g = sw[0][T * T + i];
-#pragma unroll
-    for (int j = 0; j < T; ++j) g += sw[0][i * T + j] * h0[j];
-    g1[i] = g; a1[i] = h0[i] + h0[i] * g; h1[i] = a1[i] > 0.f ? a1[i] : 0.f;
+    for (int t = 0; t < T; ++t) { go[t] = dout[((size_t)b * T + t) * HW + p]; any |= (go[t] != 0.f); }
   }
+  // rank of this thread among the block's active pixels (wave ballots + wave offsets)
+  const unsigned long long bal = __ballot(any);
+  if (lane == 0) wave_cnt[wave] = __popcll(bal);
+  __syncthreads();                                     // also: sw visible
+  int rank = __popcll(bal & ((1ull << lane) - 1ull)), nact = 0;
 #pragma unroll
-  for (int i = 0; i < T; ++i) {
-    float g = sw[1][T * T + i];
+  for (int w = 0; w < 4; ++w) { if (w < wave) rank += wave_cnt[w]; nact += wave_cnt[w]; }
+  if (nact == 0) return;                               // block-uniform
+
+  float h0[T], dg1[T], h1[T], dg2[T];
+  if (any) {
+    float g1, a1[T], g2[T], a2[T], dh1[T];
 #pragma unroll
-    for (int j = 0; j < T; ++j) g += sw[1][i * T + j] * h1[j];
-    g2[i] = g; a2[i] = h1[i] + h1[i] * g;
-  }
-  float dg2[T], dh1[T], dg1[T];
+    for (int t = 0; t < T; ++t) h0[t] = x[((size_t)b * T + t) * HW + p];
 #pragma unroll
-  for (int i = 0; i < T; ++i) {
-    const float da2 = a2[i] > 0.f ? go[i] : 0.f;
-    dg2[i] = da2 * h1[i];
-    dh1[i] = da2 * (1.f + g2[i]);
-  }
+    for (int i = 0; i < T; ++i) {
+      float g = sw[0][T * T + i];
 #pragma unroll
-  for (int j = 0; j < T; ++j) {
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < T; ++i) acc += sw[1][i * T + j] * dg2[i];
-    dh1[j] += acc;
-  }
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    const float da1 = a1[i] > 0.f ? dh1[i] : 0.f;
-    dg1[i] = da1 * h0[i];
-  }
-  // accumulate in LDS (few gauge pixels per block), then one global atomic per parameter per block
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    if (dg2[i] != 0.f) {
-      atomicAdd(&sg[1][T * T + i], dg2[i]);
-#pragma unroll
-      for (int j = 0; j < T; ++j) atomicAdd(&sg[1][i * T + j], dg2[i] * h1[j]);
+      for (int j = 0; j < T; ++j) g += sw[0][i * T + j] * h0[j];
+      g1 = g; a1[i] = h0[i] + h0[i] * g1; h1[i] = a1[i] > 0.f ? a1[i] : 0.f;
     }
-    if (dg1[i] != 0.f) {
-      atomicAdd(&sg[0][T * T + i], dg1[i]);
 #pragma unroll
-      for (int j = 0; j < T; ++j) atomicAdd(&sg[0][i * T + j], dg1[i] * h0[j]);
+    for (int i = 0; i < T; ++i) {
+      float g = sw[1][T * T + i];
+#pragma unroll
+      for (int j = 0; j < T; ++j) g += sw[1][i * T + j] * h1[j];
+      g2[i] = g; a2[i] = h1[i] + h1[i] * g;
     }
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      const float da2 = a2[i] > 0.f ? go[i] : 0.f;
+      dg2[i] = da2 * h1[i];
+      dh1[i] = da2 * (1.f + g2[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < T; ++i) acc += sw[1][i * T + j] * dg2[i];
+      dh1[j] += acc;
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      const float da1 = a1[i] > 0.f ? dh1[i] : 0.f;
+      dg1[i] = da1 * h0[i];
+    }
+  }
+  // element e of this thread: layer l = e / NP, index q = e % NP; q < T*T: weight (i, j) = (q / T, q % T) <- dg[i] * h[j]; else bias
+  float acc[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) acc[k] = 0.f;
+  for (int r0 = 0; r0 < nact; r0 += ATTN_LIST) {
+    __syncthreads();                                   // previous round consumed
+    if (any && rank >= r0 && rank < r0 + ATTN_LIST) {
+      float (&e)[4][T] = lst[rank - r0];
+#pragma unroll
+      for (int t = 0; t < T; ++t) { e[0][t] = dg1[t]; e[1][t] = h0[t]; e[2][t] = dg2[t]; e[3][t] = h1[t]; }
+    }
+    __syncthreads();
+    const int n = min(ATTN_LIST, nact - r0);
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      if (e >= 2 * NP) continue;
+      const int l = e >= NP ? 1 : 0, q = e - l * NP;
+      float a = acc[k];
+      if (q < T * T) {
+        const int i = q / T, j = q % T;
+        for (int m = 0; m < n; ++m) a += lst[m][2 * l][i] * lst[m][2 * l + 1][j];
+      } else {
+        for (int m = 0; m < n; ++m) a += lst[m][2 * l][q - T * T];
+      }
+      acc[k] = a;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    if (e >= 2 * NP || acc[k] == 0.f) continue;
+    const int l = e >= NP ? 1 : 0, q = e - l * NP;
+    float* dw = l ? dw1 : dw0;
+    float* db = l ? db1 : db0;
+    atomicAdd(q < T * T ? dw + q : db + (q - T * T), acc[k]);
   }
 }
 
