@@ -65,9 +65,51 @@ __global__ __launch_bounds__(256) void fold_fwd_tile_kernel(const float* __restr
                                                            const float* __restrict__ Dd, int O, int I, float* wp_f, float* wp_d) {
   fold_fwd_tile_body(W, D, Dd, O, I, wp_f, wp_d);
 }
+// 32 x 32 (o, i) tile for O, I multiples of 32 (the batched path).  The 16 x 16 body above reads D + D_diag (2 x 81 floats) from
+// global memory in EVERY (o, i) thread -- 162 of its 171 loads -- and stores 64-byte runs: 130 us for the eight 512-channel layers,
+// 1.7 TB/s.  Here D + D_diag of the tile's 32 input channels is summed once into LDS (conflict-free: 81 floats per channel, odd
+// pitch), a thread folds FOUR output channels against one read of it, and both packed layouts are written in full 128-byte lines.
 __global__ __launch_bounds__(256) void fold_fwd_tile_batched_kernel(const FoldBatch fb, int O, int I) {
+  __shared__ float dsum[32][81];
+  __shared__ float tile[9][32][33];
   const int L = blockIdx.z;
-  fold_fwd_tile_body(fb.W[L], fb.D[L], fb.Dd[L], O, I, fb.a[L], fb.b[L]);
+  const float* __restrict__ W = fb.W[L];
+  const float* __restrict__ D = fb.D[L];
+  const float* __restrict__ Dd = fb.Dd[L];
+  float* wp_f = fb.a[L];
+  float* wp_d = fb.b[L];
+  const int o0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+  for (int e = threadIdx.x; e < 32 * 81; e += 256) (&dsum[0][0])[e] = D[(size_t)i0 * 81 + e] + Dd[(size_t)i0 * 81 + e];
+  const int ti = threadIdx.x & 31, to = threadIdx.x >> 5;     // i = i0 + ti; o = o0 + to + 8 k, k = 0..3
+  float w[4][9];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float* wq = W + ((size_t)(o0 + to + 8 * k) * I + i0 + ti) * 9;
+#pragma unroll
+    for (int s2 = 0; s2 < 9; ++s2) w[k][s2] = wq[s2];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 9; ++m) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 9; ++s2) {
+      const float d = dsum[ti][m * 9 + s2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += d * w[k][s2];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[m][to + 8 * k][ti] = acc[k];
+  }
+  __syncthreads();
+  const int a = threadIdx.x & 31, b = threadIdx.x >> 5;
+#pragma unroll
+  for (int m = 0; m < 9; ++m)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      wp_f[((size_t)m * I + i0 + b + 8 * k) * O + o0 + a] = tile[m][a][b + 8 * k];           // wp_f[m][i][o]: lanes along o
+      if (wp_d) wp_d[((size_t)m * O + o0 + b + 8 * k) * I + i0 + a] = tile[m][b + 8 * k][a];  // wp_d[m][o][i]: lanes along i
+    }
 }
 
 __global__ void fold_fwd_kernel(const float* __restrict__ W, const float* __restrict__ D, const float* __restrict__ Dd,
@@ -133,9 +175,44 @@ __global__ __launch_bounds__(256) void fold_bwd_w_tile_kernel(const float* __res
                                                              const float* __restrict__ Dd, int O, int I, float* dW) {
   fold_bwd_w_tile_body(dwp, D, Dd, O, I, dW);
 }
+// 32 x 32 (o, i) tile, D + D_diag of the tile's input channels summed once into LDS, four output channels per thread (same
+// restructuring as fold_fwd_tile_batched_kernel; O, I multiples of 32)
 __global__ __launch_bounds__(256) void fold_bwd_w_tile_batched_kernel(const FoldBatch fb, int O, int I) {
+  __shared__ float dsum[32][81];
+  __shared__ float tile[9][32][33];
   const int L = blockIdx.z;
-  fold_bwd_w_tile_body(fb.g[L], fb.D[L], fb.Dd[L], O, I, fb.a[L]);
+  const float* __restrict__ dwp = fb.g[L];
+  const float* __restrict__ D = fb.D[L];
+  const float* __restrict__ Dd = fb.Dd[L];
+  float* dW = fb.a[L];
+  const int o0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+  for (int e = threadIdx.x; e < 32 * 81; e += 256) (&dsum[0][0])[e] = D[(size_t)i0 * 81 + e] + Dd[(size_t)i0 * 81 + e];
+  const int a = threadIdx.x & 31, b = threadIdx.x >> 5;
+#pragma unroll
+  for (int m = 0; m < 9; ++m)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[m][a][b + 8 * k] = dwp[((size_t)m * I + i0 + b + 8 * k) * O + o0 + a];    // [m][o][i], lanes along o
+  __syncthreads();
+  const int ti = threadIdx.x & 31, to = threadIdx.x >> 5;     // i = i0 + ti; o = o0 + to + 8 k
+  float g[4][9], out[4][9];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int m = 0; m < 9; ++m) { g[k][m] = tile[m][to + 8 * k][ti]; out[k][m] = 0.f; }
+#pragma unroll
+  for (int m = 0; m < 9; ++m)
+#pragma unroll
+    for (int s2 = 0; s2 < 9; ++s2) {
+      const float d = dsum[ti][m * 9 + s2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[k][s2] += g[k][m] * d;
+    }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float* o = dW + ((size_t)(o0 + to + 8 * k) * I + i0 + ti) * 9;
+#pragma unroll
+    for (int s2 = 0; s2 < 9; ++s2) o[s2] = out[k][s2];
+  }
 }
 
 // dW (O/g, I, 9) from packed dDoW: dW[q][s] = sum_m dDoW[q][m] * (D+Dd)[i][m][s]
@@ -207,9 +284,59 @@ __global__ __launch_bounds__(256) void fold_bwd_d_kernel(const float* __restrict
                                                         int groups, float* dD) {
   fold_bwd_d_body(dwp, W, O, I, groups, dD);
 }
+// dD for 32 input channels per block (O, I multiples of 32, groups 1).  The per-channel body above reads W in 36-byte pieces one
+// cache line apart (104 us for the eight 512-channel layers).  Here dDoW tiles [9][32 i][32 o] are staged through LDS with lanes
+// along o, W is read with lanes along i (both coalesced), thread = (input channel, one of 8 output-channel slices) keeps the 81
+// sums in registers over all of O, and the 8 slices are combined through LDS at the end.
 __global__ __launch_bounds__(256) void fold_bwd_d_batched_kernel(const FoldBatch fb, int O, int I) {
+  __shared__ float tile[9][32][33];                    // [m][i][o]
   const int L = blockIdx.z;
-  fold_bwd_d_body(fb.g[L], fb.W[L], O, I, 1, fb.b[L]);
+  const float* __restrict__ dwp = fb.g[L];
+  const float* __restrict__ W = fb.W[L];
+  float* dD = fb.b[L];
+  const int i0 = blockIdx.x * 32;
+  const int ti = threadIdx.x & 31, sl = threadIdx.x >> 5;       // channel i0 + ti, output slice sl: o = o0 + sl + 8 k
+  float acc[81];
+#pragma unroll
+  for (int k = 0; k < 81; ++k) acc[k] = 0.f;
+  for (int o0 = 0; o0 < O; o0 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 9; ++m)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tile[m][sl + 8 * k][ti] = dwp[((size_t)m * I + i0 + sl + 8 * k) * O + o0 + ti];   // lanes along o
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ol = sl + 8 * k;
+      float gm[9], ws[9];
+#pragma unroll
+      for (int m = 0; m < 9; ++m) gm[m] = tile[m][ti][ol];
+      const float* wq = W + ((size_t)(o0 + ol) * I + i0 + ti) * 9;
+#pragma unroll
+      for (int s2 = 0; s2 < 9; ++s2) ws[s2] = wq[s2];
+#pragma unroll
+      for (int m = 0; m < 9; ++m)
+#pragma unroll
+        for (int s2 = 0; s2 < 9; ++s2) acc[m * 9 + s2] += gm[m] * ws[s2];
+    }
+  }
+  // combine the 8 slices: [slice][i][81] floats = 83 KB would not fit beside the tile; do it in 3 passes of 27 sums through the tile
+  float* red = &tile[0][0][0];                         // 9 * 32 * 33 = 9504 floats >= 8 * 32 * 27 = 6912
+#pragma unroll
+  for (int pss = 0; pss < 3; ++pss) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 27; ++k) red[(sl * 32 + ti) * 27 + k] = acc[pss * 27 + k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 27; e += 256) {
+      const int il = e / 27, k = e - il * 27;
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v += red[(q * 32 + il) * 27 + k];
+      dD[(size_t)(i0 + il) * 81 + pss * 27 + k] = v;
+    }
+  }
 }
 
 // ---- plain (O, I, NT) <-> packed
@@ -490,7 +617,7 @@ extern "C" int p2i_doconv_fold_fwd_batched(const float* const* W, const float* c
     P2I_REQUIRE(W[i] && D[i] && D_diag[i] && wp_f[i], "null pointer (layer %d)", i);
     fb.W[i] = W[i]; fb.D[i] = D[i]; fb.Dd[i] = D_diag[i]; fb.a[i] = wp_f[i]; fb.b[i] = wp_d ? wp_d[i] : nullptr;
   }
-  hipLaunchKernelGGL(fold_fwd_tile_batched_kernel, dim3(ceil_div(I, 16), ceil_div(O, 16), n), dim3(256), 0, (hipStream_t)stream, fb, O, I);
+  hipLaunchKernelGGL(fold_fwd_tile_batched_kernel, dim3(I / 32, O / 32, n), dim3(256), 0, (hipStream_t)stream, fb, O, I);
   return launch_status();
 }
 extern "C" int p2i_doconv_fold_bwd_batched(const float* const* dwp_f, const float* const* W, const float* const* D,
@@ -504,8 +631,8 @@ extern "C" int p2i_doconv_fold_bwd_batched(const float* const* dwp_f, const floa
     fb.g[i] = dwp_f[i]; fb.W[i] = W[i]; fb.D[i] = D[i]; fb.Dd[i] = D_diag[i]; fb.a[i] = dW[i]; fb.b[i] = dD[i];
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(fold_bwd_w_tile_batched_kernel, dim3(ceil_div(I, 16), ceil_div(O, 16), n), dim3(256), 0, s, fb, O, I);
-  hipLaunchKernelGGL(fold_bwd_d_batched_kernel, dim3(I, 1, n), dim3(256), 0, s, fb, O, I);
+  hipLaunchKernelGGL(fold_bwd_w_tile_batched_kernel, dim3(I / 32, O / 32, n), dim3(256), 0, s, fb, O, I);
+  hipLaunchKernelGGL(fold_bwd_d_batched_kernel, dim3(I / 32, 1, n), dim3(256), 0, s, fb, O, I);
   return launch_status();
 }
 
