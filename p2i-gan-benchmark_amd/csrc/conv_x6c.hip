@@ -78,6 +78,21 @@ int x6_split_weights(const float* wp, uint16_t* wb, int ntaps, int Ck, int CmPad
   return launch_status();
 }
 
+// Kernel argument of patch_gemm_x6c_kernel: only what this kernel reads (~300 bytes).  The engine-wide PatchGeom is 2 KB (27-tap
+// tables for four classes); passed by value it stayed in SGPRs only as long as the kernel was simple -- see DESIGN.md.
+struct X6cGeom {
+  const float* src; float* dst; const uint16_t* wb; const float* bias; const float* res; const float* mask_y;
+  unsigned wb_bytes;
+  int act_epi, mask_act;
+  int B, Ck, Cm, CmPad;
+  int sH, sW, dT, dH, dW, nH, nW;
+  int ljb, ljh, ljw, eH, eW, CSl, bH, bW, nth, ntw;
+  unsigned mg_ew, mg_eh;
+  int ntaps_w, ksplit;
+  int tap_off[9];
+  int tap_w[9];
+};
+
 // Tile variants <NW waves, TM 32-channel tiles per wave>: a workgroup computes (32 TM) channels x (32 NW) positions, wave = 32 TM
 // channels x 32 positions.  <8,2> (64 x 256) is the efficient one (0.75 operand reads per MFMA); <8,1> (32 x 256) gives the
 // 256-channel level (32x32 maps, 128 tiles of 64 x 256 at B = 8) one workgroup per CU: 72 vs 103 us (<8,2>) vs 89 us (f32 engine).
@@ -102,7 +117,7 @@ __device__ __forceinline__ void x6c_wait_vm(int n) {
 }
 
 template <int NW, int TM>
-__global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const PatchGeom g) {
+__global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef P2I_STAMP
   unsigned long long st_entry, st_prev, st_wait = 0, st_bar = 0, st_issue = 0, st_mfma = 0, st_loop0;
@@ -434,7 +449,7 @@ __global__ __launch_bounds__(256) void x6c_post_act_kernel(float* __restrict__ y
 }
 
 template <int NW, int TM>
-static void x6c_launch(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s) {
+static void x6c_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)patch_gemm_x6c_kernel<NW, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -493,8 +508,16 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
     if (post_act != P2I_ACT_NONE) { post_res = g.res; g.res = nullptr; g.act_epi = P2I_ACT_NONE; }   // act(sum + bias) + res: second pass
   }
   if (plan6) { plan6[0] = 32 * tv.TM; plan6[1] = 32 * tv.NW; plan6[2] = pk.ksplit; plan6[3] = 16; plan6[4] = 9; plan6[5] = 7; }
-  if (tv.TM == 2) x6c_launch<8, 2>(g, grid, lds, s);
-  else x6c_launch<8, 1>(g, grid, lds, s);
+  X6cGeom k{};
+  k.src = g.src; k.dst = g.dst; k.wb = g.wb; k.bias = g.bias; k.res = g.res; k.mask_y = g.mask_y;
+  k.wb_bytes = g.wb_bytes; k.act_epi = g.act_epi; k.mask_act = g.mask_act;
+  k.B = g.B; k.Ck = g.Ck; k.Cm = g.Cm; k.CmPad = g.CmPad;
+  k.sH = g.sH; k.sW = g.sW; k.dT = g.dT; k.dH = g.dH; k.dW = g.dW; k.nH = g.nH; k.nW = g.nW;
+  k.ljb = g.ljb; k.ljh = g.ljh; k.ljw = g.ljw; k.eH = g.eH; k.eW = g.eW; k.CSl = g.CSl; k.bH = g.bH; k.bW = g.bW;
+  k.nth = g.nth; k.ntw = g.ntw; k.mg_ew = g.mg_ew; k.mg_eh = g.mg_eh; k.ntaps_w = g.ntaps_w; k.ksplit = g.ksplit;
+  for (int i = 0; i < 9; ++i) { k.tap_off[i] = g.tap_off[i]; k.tap_w[i] = g.tap_w[i]; }
+  if (tv.TM == 2) x6c_launch<8, 2>(k, grid, lds, s);
+  else x6c_launch<8, 1>(k, grid, lds, s);
   if (post_act != P2I_ACT_NONE) {
     const long long n4 = n_dst / 4;
     const long long blocks = (n4 + 255) / 256;
