@@ -212,9 +212,14 @@ static int run_patch_gemm(PatchGeom g, const ClassSpec& cs, hipStream_t s);
 // Returns 1 if the merged DMA launch is not possible (caller falls back to one launch per class).
 static int run_patch_gemm_classes(PatchGeom g, const ClassSpec* css, int ncls, hipStream_t s) {
   if (g.src_y != nullptr || ncls > MAX_CLASSES) return 1;
-  if (const X6Ctx& xc = x6_ctx(); xc.wb != nullptr && ncls == 1) {        // inside a p2i_conv_*_x6 call: bf16-split kernel first
-    const int rc = run_patch_gemm_x6c(g, css[0], xc.wb, xc.ntaps_w, g_last_plan, s);
-    if (rc != 1) return rc;
+  if (const X6Ctx& xc = x6_ctx(); xc.wb != nullptr) {        // inside a p2i_conv_*_x6 call: bf16-split kernel first, one launch per class
+    bool all = true;                                        // (all classes or none)
+    for (int q = 0; q < ncls && all; ++q) all = run_patch_gemm_x6c(g, css[q], xc.wb, xc.ntaps_w, nullptr, s, true) == 0;
+    if (all) {
+      for (int q = 0; q < ncls; ++q)
+        if (const int rc = run_patch_gemm_x6c(g, css[q], xc.wb, xc.ntaps_w, g_last_plan, s)) return rc == 1 ? P2I_EINVAL : rc;
+      return P2I_OK;
+    }
   }
   const ClassSpec& c0s = css[0];
   g.mT = c0s.mT; g.mH = c0s.mH; g.mW = c0s.mW;

@@ -236,7 +236,7 @@ struct X6Ctx { const uint16_t* wb; int ntaps_w; };
 X6Ctx& x6_ctx();
 
 // 3x3 stride-1 2-D layers on the bf16 matrix pipe, chunk/tap-row pipeline (conv_x6c.hip); returns 1 when it does not apply
-int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s);
+int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s, bool dry = false);
 bool x6c_would_take(const p2i_conv_desc* d, bool dgrad, int act_epi);
 
 // strided dgrad with the parity classes fused in one workgroup (conv_fused.hip); returns 1 when it does not apply

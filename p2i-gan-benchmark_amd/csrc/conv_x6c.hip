@@ -89,6 +89,9 @@ struct X6cGeom {
   int ljb, ljh, ljw, eH, eW, CSl, bH, bW, nth, ntw;
   unsigned mg_ew, mg_eh;
   int ntaps_w, ksplit;
+  // time axis: 'images' of the tile loop are (b, lt) pairs, lt in [0, nT); the taps form ns slices of 3x3 spatial taps, slice j reads
+  // source frame lt * mT + sdt[j] (zero outside [0, sT)) and the weight taps swt[j] + tap_w[0..8]; destination frame lt * oT + pT
+  int sT, nT, mT, oT, pT, ns, sdt0, sdt1, sdt2, swt0, swt1, swt2;
   int tap_off[9];
   int tap_w[9];
 };
@@ -146,15 +149,19 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
   const int sHW = g.sH * g.sW;
   const int src_h0 = j0h + g.bH, src_w0 = j0w + g.bW;
   const int KCt = g.Ck >> 3;
-  const int c0 = blockIdx.z * ((g.Ck >> 4) / g.ksplit);   // split-K: first channel chunk of this workgroup
+  const int cps = g.Ck >> 4;                               // 16-channel chunks per tap slice
+  const int cs = g.sT * sHW;                               // source channel stride
+  const int nimg = g.B * g.nT;
+  const int c0 = blockIdx.z * ((g.ns * cps) / g.ksplit);   // split-K: first chunk of this workgroup (chunks run slice-major)
 
   for (int e = tid; e < CSl; e += NTHR) {
     const int row = fast_div(e, g.mg_ew);
     const int ew = e - row * g.eW;
     const int jb = fast_div(row, g.mg_eh);
     const int eh = row - jb * g.eH;
-    const int b = j0b + jb, h = src_h0 + eh, w = src_w0 + ew;
-    ptab[e] = (b < g.B && (unsigned)h < (unsigned)g.sH && (unsigned)w < (unsigned)g.sW) ? (b * g.Ck) * sHW + h * g.sW + w : -1;
+    const int n = j0b + jb, h = src_h0 + eh, w = src_w0 + ew;          // image n = (b, lt)
+    const int b = n / g.nT, lt = n - b * g.nT;
+    ptab[e] = (n < nimg && (unsigned)h < (unsigned)g.sH && (unsigned)w < (unsigned)g.sW) ? ((b * g.Ck) * g.sT + lt * g.mT) * sHW + h * g.sW + w : -1;
   }
   // this wave's 32 output positions
   const int pix = wave * 32 + l31;
@@ -178,34 +185,43 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
   __syncthreads();                                                        // ptab visible
 
   // patch items of this thread: (k-group kg, patch pixel e); 8 channel values each
-  int it_off[NI], it_dst[NI];
+  int it_off[NI], it_dst[NI], it_f0[NI];
 #pragma unroll
   for (int it = 0; it < NI; ++it) {
     const int item = it * NTHR + tid;
     const int kg = item >= CSl ? 1 : 0, e = item - kg * CSl;
     const bool in = item < 2 * CSl;
     const int po = in ? ptab[e] : -1;
-    it_off[it] = po < 0 ? -1 : po + kg * 8 * sHW;
+    it_off[it] = po < 0 ? -1 : po + kg * 8 * cs;
     it_dst[it] = in ? kg * CSl + e : -1;
+    const int jbi = fast_div(fast_div(in ? e : 0, g.mg_ew), g.mg_eh);
+    it_f0[it] = ((j0b + jbi) % g.nT) * g.mT;                       // source frame at slice offset 0
   }
   // The patch loads are issued from inline asm like the DMAs, so that EVERY vector-memory operation of the loop is counted by
   // hand: next to asm DMAs hipcc would wait vmcnt(0) before the first use of a plain load's result and drain the weight ring.
   // pv is not touched between load_patch and the counted wait in front of split_patch.
   float pv[NI][8];
-  int it_voff[NI];
-#pragma unroll
-  for (int it = 0; it < NI; ++it) it_voff[it] = (it_off[it] < 0 ? 0 : it_off[it]) * 4;
+  bool pok[NI];                                                   // the loaded chunk's slice frame exists for this item
   auto load_patch = [&](int c) {
-    const float* sc = g.src + (size_t)(c0 + c) * 16 * sHW;
+    const int cg = c0 + c;
+    const int j = cg >= 2 * cps ? 2 : (cg >= cps ? 1 : 0);            // tap slice (wave-uniform)
+    const int dt = j == 2 ? g.sdt2 : (j == 1 ? g.sdt1 : g.sdt0);
+    const float* sc = g.src + (size_t)(cg - j * cps) * 16 * cs;
+    int voff[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      pok[it] = it_off[it] >= 0 && (unsigned)(it_f0[it] + dt) < (unsigned)g.sT;
+      voff[it] = pok[it] ? (it_off[it] + dt * sHW) * 4 : 0;          // non-negative for valid items; idle items read element 0
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const float* sq = sc + (size_t)q * sHW;
+      const float* sq = sc + (size_t)q * cs;
       const unsigned long long sq_u = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)sq) & 0xffffffffull;
       const unsigned long long sq_hi = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)sq >> 32));
       const unsigned long long sbase = sq_u | (sq_hi << 32);
 #pragma unroll
       for (int it = 0; it < NI; ++it)
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(pv[it][q]) : "v"(it_voff[it]), "s"(sbase) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(pv[it][q]) : "v"(voff[it]), "s"(sbase) : "memory");
     }
   };
   auto split_patch = [&](u32x4c* pb) {
@@ -214,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
       if (it_dst[it] < 0) continue;
       float v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = it_off[it] < 0 ? 0.f : pv[it][q];
+      for (int q = 0; q < 8; ++q) v[q] = pok[it] ? pv[it][q] : 0.f;
       u32x4c h, mi, lo;
       split8c(v, h, mi, lo);
       pb[it_dst[it]] = h;
@@ -240,13 +256,17 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
     w_dst[r] = wbuf_la + 16u * (unsigned)(u * 64);
   }
   const int w_cstep = 2 * g.CmPad * 16;                                // one 16-channel chunk further
+  const int w_tstep = KCt * g.CmPad * 16;                              // one weight tap further
   auto issue_w = [&](int c, int b, int sb) {
+    const int cg = c0 + c;
+    const int j = cg >= 2 * cps ? 2 : (cg >= cps ? 1 : 0);
+    const int soff = (cg - j * cps) * w_cstep + (j == 2 ? g.swt2 : (j == 1 ? g.swt1 : g.swt0)) * w_tstep;
 #pragma unroll
     for (int r = 0; r < NWR; ++r)
-      if (wave + NW * r < NWI) dma_b128(rs_w, w_dst[r] + 16u * (unsigned)(sb * WST), wvoff, w_soff[r][b] + (c0 + c) * w_cstep);
+      if (wave + NW * r < NWI) dma_b128(rs_w, w_dst[r] + 16u * (unsigned)(sb * WST), wvoff, w_soff[r][b] + soff);
   };
 
-  const int nch = (g.Ck >> 4) / g.ksplit;             // this workgroup's chunks: [c0, c0 + nch)
+  const int nch = (g.ns * cps) / g.ksplit;            // this workgroup's chunks: [c0, c0 + nch)
   const int nst = 3 * nch;
   const int nw_mine = (NWI / NW) + (wave < NWI % NW ? 1 : 0);          // this wave's DMA instructions per weight batch
   constexpr int NPL = 8 * NI;                                           // patch loads per thread and chunk
@@ -364,10 +384,11 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
 #endif
 
   // ---- epilogue (shared with the f32 engine)
-  const int gw = j0w + pjw, gh = j0h + pjh, gb = j0b + pjb;
-  const bool pvld = gb < g.B && gh < g.nH && gw < g.nW;
-  const int dHW = g.dH * g.dW;
-  const size_t pos = (size_t)gb * g.Cm * dHW + (size_t)gh * g.dW + gw;
+  const int gw = j0w + pjw, gh = j0h + pjh, gn = j0b + pjb;
+  const bool pvld = gn < nimg && gh < g.nH && gw < g.nW;
+  const int dHW = g.dT * g.dH * g.dW;                                   // destination channel stride
+  const int gb_ = gn / g.nT, glt = gn - gb_ * g.nT;
+  const size_t pos = (size_t)gb_ * g.Cm * dHW + (size_t)(glt * g.oT + g.pT) * g.dH * g.dW + (size_t)gh * g.dW + gw;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
     if (g.ksplit > 1)       // partial sum: bias / residual ride with split 0, the mask factor (0/1 for relu') distributes over the sum
@@ -423,12 +444,20 @@ static X6cPick x6c_pick(int B, int nH, int nW, int Cm, int Ck, bool linear_epi) 
 // cheap host-side test used before the weights are split: would run_patch_gemm_x6c take this layer?
 bool x6c_would_take(const p2i_conv_desc* d, bool dgrad, int act_epi) {
   static const int on = getenv("P2I_CONV_X6C") ? atoi(getenv("P2I_CONV_X6C")) : 1;
-  if (!on || d->kt != 1 || d->kh != 3 || d->kw != 3 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->Ti != 1 || d->To != 1) return false;
+  (void)act_epi;                                       // (an activation is applied by a second pass when the launch is split-K)
+  if (!on || d->kh != 3 || d->kw != 3 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1) return false;
+  const bool flat = d->kt == 1 && d->st == 1 && d->pt == 0;           // 2-D layer (or frames convolved independently)
+  const bool vol = d->kt == 3 && d->pt == 1 && d->st <= 2;            // 3 x 3 x 3, t stride 1 or 2: tap slices along t
+  if (!flat && !vol) return false;
   const int Ck = dgrad ? d->Cout : d->Cin, Cm = dgrad ? d->Cin : d->Cout;
   const int nH = dgrad ? d->Hi : d->Ho, nW = dgrad ? d->Wi : d->Wo;
   if ((Ck & 15) != 0 || Ck < 16) return false;
-  (void)act_epi;                                       // (an activation is applied by a second pass when the launch is split-K)
-  return x6c_pick(d->B, nH, nW, Cm, Ck, true).v >= 0;
+  // images of one launch: forward all output frames; data gradient one t-parity class of the input frames
+  const int nT = dgrad ? d->Ti / d->st : d->To;
+  if (nT < 1) return false;
+  const int ns = flat ? 1 : (dgrad && d->st == 2 ? 1 : 3);           // fewest slices of a launch (conservative for the chunk-parity test)
+  const bool whole = !dgrad || d->st == 1;
+  return x6c_pick(d->B * nT, nH, nW, Cm, ns * Ck, whole).v >= 0;
 }
 
 // second pass of a split-K forward whose epilogue has an activation: y = act(sum of the two partial sums [+ bias, added by split 0])
@@ -459,11 +488,13 @@ static void x6c_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
 }
 
 // returns 1 when the layer is not an x6c case (caller continues with the other engines)
-int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s) {
+int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s, bool dry) {
   static const int on = getenv("P2I_CONV_X6C") ? atoi(getenv("P2I_CONV_X6C")) : 1;
-  if (!on || wb == nullptr || g.src_y != nullptr || cs.ntaps != 9 || (g.Ck & 15) != 0 || g.Ck < 16) return 1;
-  if (cs.mT != 1 || cs.mH != 1 || cs.mW != 1 || cs.oT != 1 || cs.oH != 1 || cs.oW != 1 || cs.pT || cs.pH || cs.pW) return 1;
-  if (g.sT != 1 || g.dT != 1 || cs.nT != 1) return 1;
+  if (!on || (!dry && wb == nullptr) || g.src_y != nullptr || (g.Ck & 15) != 0 || g.Ck < 16) return 1;
+  // spatially a 3x3 stride-1 layer; along t: any source multiplier / destination stride / offset, taps in 1..3 slices of 9
+  if (cs.mH != 1 || cs.mW != 1 || cs.oH != 1 || cs.oW != 1 || cs.pH || cs.pW) return 1;
+  if (cs.ntaps != 9 && cs.ntaps != 18 && cs.ntaps != 27) return 1;
+  const int ns = cs.ntaps / 9;
   int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   for (int i = 0; i < 9; ++i) {
     const int d[3] = {cs.dt[i], cs.dh[i], cs.dw[i]};
@@ -472,14 +503,25 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
       if (i == 0 || d[k] > hi[k]) hi[k] = d[k];
     }
   }
-  if (lo[0] != 0 || hi[0] != 0 || hi[1] - lo[1] != 2 || hi[2] - lo[2] != 2) return 1;
+  if (lo[0] != hi[0] || hi[1] - lo[1] != 2 || hi[2] - lo[2] != 2) return 1;
+  for (int j = 0; j < ns; ++j)                          // every slice: one source frame offset, slice 0's spatial taps, weight taps shifted as a block
+    for (int i = 0; i < 9; ++i) {
+      const int q = 9 * j + i;
+      if (cs.dt[q] != cs.dt[9 * j] || cs.dh[q] != cs.dh[i] || cs.dw[q] != cs.dw[i] || cs.tw[q] - cs.tw[i] != cs.tw[9 * j] - cs.tw[0]) return 1;
+    }
   const long long n_dst = (long long)g.B * g.Cm * g.dT * g.dH * g.dW;
-  const X6cPick pk = x6c_pick(g.B, cs.nH, cs.nW, g.Cm, g.Ck, (n_dst & 3) == 0);
+  const long long nimg = (long long)g.B * cs.nT;
+  if (nimg >= (1 << 24)) return 1;
+  // split-K zeroes the WHOLE destination: only when this launch owns all of it (no destination stride / offset along t)
+  const X6cPick pk = x6c_pick((int)nimg, cs.nH, cs.nW, g.Cm, ns * g.Ck, (n_dst & 3) == 0 && cs.oT == 1 && cs.pT == 0 && cs.nT == g.dT);
   if (pk.v < 0) return 1;
+  const unsigned long long sbytes = 4ull * g.B * g.Ck * g.sT * g.sH * g.sW;
+  if (sbytes >= 0x7FFFFFF0ull || 4ull * (unsigned long long)n_dst >= 0x7FFFFFF0ull) return 1;
+  if (dry) return 0;
   const X6cVariant& tv = kX6cVariants[pk.v];
   const int jb = pk.jb, jh = pk.jh, jw = pk.jw;
-  g.nT = 1; g.nH = cs.nH; g.nW = cs.nW;
-  g.mT = g.mH = g.mW = 1; g.oT = g.oH = g.oW = 1; g.pT = g.pH = g.pW = 0;
+  g.nT = cs.nT; g.nH = cs.nH; g.nW = cs.nW;
+  g.mT = cs.mT; g.mH = g.mW = 1; g.oT = cs.oT; g.oH = g.oW = 1; g.pT = cs.pT; g.pH = g.pW = 0;
   g.ljb = ilog2(jb); g.ljt = 0; g.ljh = ilog2(jh); g.ljw = ilog2(jw);
   g.eT = 1; g.eH = jh + 2; g.eW = jw + 2;
   g.CSl = pk.csl;
@@ -490,14 +532,15 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   }
   g.ntaps = 9;
   g.nth = ceil_div(cs.nH, jh); g.ntw = ceil_div(cs.nW, jw); g.ntt = 1;
-  const int ntb = ceil_div(g.B, jb);
+  const int ntb = ceil_div((int)nimg, jb);
   g.ksplit = pk.ksplit;
   const dim3 grid((unsigned)(ntb * g.nth * g.ntw), (unsigned)ceil_div(g.Cm, 32 * tv.TM), (unsigned)pk.ksplit);
-  const unsigned long long sbytes = 4ull * g.B * g.Ck * g.sH * g.sW;
-  if (sbytes >= 0x7FFFFFF0ull) return 1;
   g.mg_ew = magic_u16(g.eW); g.mg_eh = magic_u16(g.eH);
   g.wb = wb; g.ntaps_w = ntaps_w;
-  g.wb_bytes = (2u * (unsigned)ntaps_w + 9u) * (unsigned)g.Ck * (unsigned)g.CmPad * 2u;   // planes 0..2 of this layer inside a stack of ntaps_w taps
+  // planes 0..2 of this layer inside a stack of ntaps_w taps; the layer's own taps reach up to max(tw) + 1
+  int tw_max = 0;
+  for (int i = 0; i < cs.ntaps; ++i) tw_max = cs.tw[i] > tw_max ? cs.tw[i] : tw_max;
+  g.wb_bytes = (2u * (unsigned)ntaps_w + (unsigned)tw_max + 1u) * (unsigned)g.Ck * (unsigned)g.CmPad * 2u;
   g.nclass = 1;
   const int ring = tv.TM == 2 ? 4 : 6;
   const size_t lds = sizeof(float) * (size_t)((g.CSl + 3) & ~3) + 16 * (size_t)(ring * 18 * 32 * tv.TM + 2 * 6 * g.CSl);
@@ -516,6 +559,10 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   k.ljb = g.ljb; k.ljh = g.ljh; k.ljw = g.ljw; k.eH = g.eH; k.eW = g.eW; k.CSl = g.CSl; k.bH = g.bH; k.bW = g.bW;
   k.nth = g.nth; k.ntw = g.ntw; k.mg_ew = g.mg_ew; k.mg_eh = g.mg_eh; k.ntaps_w = g.ntaps_w; k.ksplit = g.ksplit;
   for (int i = 0; i < 9; ++i) { k.tap_off[i] = g.tap_off[i]; k.tap_w[i] = g.tap_w[i]; }
+  k.sT = g.sT; k.nT = g.nT; k.mT = g.mT; k.oT = g.oT; k.pT = g.pT; k.ns = ns;
+  k.sdt0 = cs.dt[0]; k.swt0 = 0;
+  k.sdt1 = ns > 1 ? cs.dt[9] : 0; k.swt1 = ns > 1 ? cs.tw[9] - cs.tw[0] : 0;
+  k.sdt2 = ns > 2 ? cs.dt[18] : 0; k.swt2 = ns > 2 ? cs.tw[18] - cs.tw[0] : 0;
   if (tv.TM == 2) x6c_launch<8, 2>(k, grid, lds, s);
   else x6c_launch<8, 1>(k, grid, lds, s);
   if (post_act != P2I_ACT_NONE) {

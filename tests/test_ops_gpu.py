@@ -47,6 +47,8 @@ CONV_CASES = [
     ("d3d_first_odd", 3, 1, 1, 20, (5, 17, 22), (3, 3, 3), (1, 2, 2), (1, 1, 1), "leaky", True, False),       # T % 4 != 0, odd H, Cout < 32
     ("d3d_mid", 3, 2, 32, 64, (4, 16, 16), (3, 3, 3), (1, 2, 2), (1, 1, 1), "leaky", True, False),
     ("d3d_tstride", 3, 2, 16, 16, (8, 8, 8), (3, 3, 3), (2, 1, 1), (1, 1, 1), "leaky", True, False),
+    ("d3d_tstride16", 3, 2, 32, 48, (6, 16, 16), (3, 3, 3), (2, 1, 1), (1, 1, 1), "leaky", True, False),   # x6c with tap slices along t (stride 2 in t)
+    ("d3d_t1_16", 3, 1, 16, 32, (5, 16, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1), "none", True, True),            # x6c with tap slices, stride 1, odd T
     ("d3d_1x1x1", 3, 2, 128, 1, (4, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0), "none", True, False),
 ]
 
@@ -194,6 +196,7 @@ def test_conv_fwd_dgrad_wgrad(ops, engine, case):
     yg = ops.conv_fwd(spec, xg, wp_f, bias.detach().to(dev) if has_bias else None, res.to(dev) if has_res else None, act_code)
     x6c_layer = engine.startswith("x6c") and nd == 2 and k == (3, 3) and st == (1, 1) and name not in ("g3x3_tiny4", "g3x3_w128", "d2d_to1", "g3x3_1024_atomic")
     # (those three: a 256-position tile spans 16 or 4 images / is 2 x 128 + halo -- patches above the 384-pixel limit, f32 engine)
+    x6c_layer = x6c_layer or (engine.startswith("x6c") and name in ("d3d_tstride16", "d3d_t1_16"))
     if x6c_layer and Cin % 16 == 0:
         assert _last_plan(ops)[5] == 7, (name, _last_plan(ops))
     assert rel_err(yg.cpu().numpy(), out.detach().numpy()) < TOL_OP
