@@ -513,7 +513,11 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   const long long nimg = (long long)g.B * cs.nT;
   if (nimg >= (1 << 24)) return 1;
   // split-K zeroes the WHOLE destination: only when this launch owns all of it (no destination stride / offset along t)
-  const X6cPick pk = x6c_pick((int)nimg, cs.nH, cs.nW, g.Cm, ns * g.Ck, (n_dst & 3) == 0 && cs.oT == 1 && cs.pT == 0 && cs.nT == g.dT);
+  // ... and only when the destination aliases neither epilogue operand: every other engine reads res[i] / mask_y[i] and then writes
+  // dst[i] in the same thread, so in-place residual / mask works there; a zero-filled destination would be read back as zeros
+  const bool alias = g.dst == g.res || g.dst == g.mask_y;
+  const X6cPick pk = x6c_pick((int)nimg, cs.nH, cs.nW, g.Cm, ns * g.Ck,
+                              (n_dst & 3) == 0 && cs.oT == 1 && cs.pT == 0 && cs.nT == g.dT && !alias);
   if (pk.v < 0) return 1;
   const unsigned long long sbytes = 4ull * g.B * g.Ck * g.sT * g.sH * g.sW;
   if (sbytes >= 0x7FFFFFF0ull || 4ull * (unsigned long long)n_dst >= 0x7FFFFFF0ull) return 1;

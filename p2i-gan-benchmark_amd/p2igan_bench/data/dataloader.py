@@ -80,7 +80,9 @@ class P2IDataModule:
             return None
         base = ds.dataset if isinstance(ds, Subset) else ds
         collate = _collate_variable if getattr(base, "is_zarr", False) and getattr(base, "sample_length", None) is None else None
-        sampler = ShardedSampler(len(ds), self.rank, self.world, shuffle, self.cfg.get("seed", 42)) if self.world > 1 else None
+        # evaluation loaders (drop_last=False) shard without truncation or padding: every sample is seen exactly once
+        sampler = ShardedSampler(len(ds), self.rank, self.world, shuffle, self.cfg.get("seed", 42), even=drop_last is not False) \
+            if self.world > 1 else None
         return DataLoader(ds, batch_size=bs, shuffle=shuffle and sampler is None, sampler=sampler, num_workers=self.num_workers,
                           pin_memory=self.pin_memory, persistent_workers=self.num_workers > 0 and self.persistent_workers,
                           prefetch_factor=self.prefetch_factor if self.num_workers > 0 else None, collate_fn=collate,
@@ -91,7 +93,7 @@ class P2IDataModule:
         return self._loader(self.train_dataset, True, self.cfg["train"]["batch_size"])
 
     def val_dataloader(self):
-        # evaluation splits keep their tail batch on every rank (the trainer all-reduces (sum, count))
+        # evaluation splits keep their tail batch on every rank (the trainer all-reduces (sum, sample count))
         return self._loader(self.valid_dataset, self.valid_shuffle, self.cfg["train"]["batch_size"], drop_last=False)
 
     def test_dataloader(self):
@@ -99,7 +101,10 @@ class P2IDataModule:
 
 
 class _WorkerSeed:
-    """worker_init_fn: numpy's and python's generators (mask draws, crop offsets) seeded per (rank, worker)."""
+    """worker_init_fn: numpy's and python's generators (mask draws, crop offsets) seeded per (epoch, rank, worker).
+    torch has already seeded the worker with base_seed + worker_id by the time this runs, and base_seed is drawn anew every
+    time the loader's workers are (re)started -- every epoch unless persistent_workers -- so deriving from torch.initial_seed()
+    keeps the epoch-to-epoch variation of the reference (torch's default worker seeding) and adds the rank term on top."""
 
     def __init__(self, seed, rank):
         self.seed, self.rank = seed, rank
@@ -107,7 +112,7 @@ class _WorkerSeed:
     def __call__(self, worker_id):
         import random
         import numpy as np
-        s = (self.seed + 1000003 * self.rank + 7919 * (worker_id + 1)) % (2 ** 32)
+        s = (torch.initial_seed() + 1000003 * self.rank) % (2 ** 32)
         random.seed(s)
         np.random.seed(s)
 

@@ -178,7 +178,7 @@ class TrainEngine:
                 lg, cg = net_fns.discriminator_forward(D, preds, need_x=True, need_p=False, pool=True)
                 adv, dlg = ops.gan_loss_g(lg, self.adv_weight, self.gan_type, self.real_label)
                 # d(rec)/d(preds) rides into the discriminator's first-layer dgrad as its additive term
-                dgen, _, _, _ = net_fns.discriminator_backward(D, cg, dlg, need_x=True, needs=[False] * (2 * 10 + 1), dx_add=dpred)
+                dgen, _, _, _ = net_fns.discriminator_backward(D, cg, dlg, need_x=True, needs=[False] * (2 * sum(map(len, D.layers())) + 1), dx_add=dpred)
                 del cg
                 loss_g = ops.add2(out3[2:3], adv)
                 out.update(loss_d=loss_d.reshape(()), adv=adv.reshape(()), logits_real=lr_, logits_fake=lf)

@@ -89,16 +89,20 @@ def broadcast_module_state(module: nn.Module, flat: Optional[FlatParams] = None,
 
 class ShardedSampler:
     """Rank-sharded index stream: every rank draws the SAME seeded permutation per epoch and takes the
-    slice rank::world of it, truncated so that all ranks see the same number of samples."""
+    slice rank::world of it.  even=True (training): truncated so that all ranks see the same number of samples (every
+    step holds a collective).  even=False (evaluation): nothing is dropped and nothing is repeated -- ranks may differ
+    by one sample, and the caller all-reduces (sum, sample count)."""
 
-    def __init__(self, n: int, rank: int, world: int, shuffle: bool = True, seed: int = 0):
-        self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, rank, world, shuffle, seed, 0
+    def __init__(self, n: int, rank: int, world: int, shuffle: bool = True, seed: int = 0, even: bool = True):
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch, self.even = n, rank, world, shuffle, seed, 0, even
 
     def set_epoch(self, epoch: int):
         self.epoch = epoch
 
     def __len__(self):
-        return self.n // self.world
+        if self.even:
+            return self.n // self.world
+        return len(range(self.rank, self.n, self.world))
 
     def __iter__(self) -> Iterator[int]:
         if self.shuffle:
@@ -106,5 +110,7 @@ class ShardedSampler:
             idx = torch.randperm(self.n, generator=g).tolist()
         else:
             idx = list(range(self.n))
+        if not self.even:
+            return iter(idx[self.rank::self.world])
         per = self.n // self.world
         return iter(idx[self.rank:per * self.world:self.world])

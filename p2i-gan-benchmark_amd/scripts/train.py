@@ -130,21 +130,26 @@ class Trainer:
         return [t.permute(0, 1, 4, 2, 3).contiguous().to(self.device, non_blocking=True) for t in batch]   # train.py:468-473
 
     def _evaluate_rec_loss(self, loader, max_frames=None):
-        """train.py:369-382 on the HIP path; under data parallelism (sum, count) are all-reduced so that every rank (and the
-        best.pt decision on rank 0) sees the loss over the whole split.  Returns (mean loss, number of batches)."""
+        """train.py:369-382 on the HIP path; under data parallelism the evaluation loaders shard the split without padding and
+        (loss sum weighted by samples, sample count) are all-reduced, so that every rank (and the best.pt decision on rank 0)
+        sees the mean over the whole split with every sample counted once.  Returns (mean loss, number of samples)."""
         tot = torch.zeros(2, dtype=torch.float64, device=self.device)
+        skipped = 0
         for batch in loader:
             fr, mk, ms = self._batch(batch)
             if max_frames is not None and fr.shape[1] > max_frames:      # test events are full-length: first window only
                 fr, mk, ms = (t[:, :max_frames].contiguous() for t in (fr, mk, ms))
             if fr.shape[1] != self.generator.length:
+                skipped += fr.shape[0]
                 continue
-            tot[0] += self.engine.eval_rec_loss(fr, mk, ms).double()
-            tot[1] += 1
+            tot[0] += self.engine.eval_rec_loss(fr, mk, ms).double() * fr.shape[0]     # batch mean -> sample-weighted sum
+            tot[1] += fr.shape[0]
+        if skipped:
+            logging.warning("evaluation skipped %d sample(s) whose length differs from the generator's %d frames", skipped, self.generator.length)
         if self.world > 1:
             torch.distributed.all_reduce(tot)
-        nb = int(tot[1])
-        return (float(tot[0]) / nb if nb else float("nan")), nb
+        ns = int(tot[1])
+        return (float(tot[0]) / ns if ns else float("nan")), ns
 
     def train(self, tracker):
         for epoch in range(1, self.max_epochs + 1):
@@ -173,7 +178,7 @@ class Trainer:
                 if nb:                                      # an empty split must not pin best.pt at 0.0
                     val_loss = vl
                     tracker.metric("val/loss", val_loss, self.global_step)
-                    logging.info("Validation done | val_loss=%.4f (%d batches)", val_loss, nb)
+                    logging.info("Validation done | val_loss=%.4f (%d samples)", val_loss, nb)
             if self.run_test and self.test_loader is not None and self.test_interval > 0 and epoch % self.test_interval == 0:
                 tl, nb = self._evaluate_rec_loss(self.test_loader, max_frames=self.generator.length)
                 if nb:

@@ -102,3 +102,37 @@ def test_device_assemble_mode_ships_uint8_with_identical_masks(tmp_path):
     assert fr_u8.dtype == torch.uint8 and mk_u8.dtype == torch.uint8 and fr_u8.shape == (16, 32, 32)
     assert torch.equal(fr_u8.float() / 255.0, video[..., 0]) and torch.equal(mk_u8.float(), mask[..., 0])
     assert torch.equal((fr_u8.float() / 255.0) * mk_u8.float(), masked[..., 0])
+
+
+def test_worker_seeding_varies_per_epoch_and_rank():
+    """with num_workers > 0 and persistent_workers off the workers restart every epoch; their numpy / python
+    generators must NOT restart from the same seed (torch's default worker seeding, which the reference relies on, differs per
+    epoch).  Two epochs over the same samples must draw different 'sti' masks; two ranks must differ too."""
+    from p2igan_bench.data.dataloader import P2IDataModule
+    cfg = {"seed": 5, "data": {"train": {"data_root": "synthetic://4", "w": 32, "h": 32, "sample_length": 16, "mask": {"type": "sti", "block_sizes": [8]}}},
+           "train": {"batch_size": 2, "num_workers": 2, "persistent_workers": False, "pin_memory": False}}
+
+    def epoch_masks(rank, world):
+        torch.manual_seed(123)                         # same base-seed stream for both ranks: only the rank term separates them
+        dl = P2IDataModule(cfg, rank, world)._loader(P2IDataModule(cfg, rank, world).train_dataset, False, 2)
+        return [torch.cat([b[2] for b in dl]) for _ in range(2)]
+
+    e0, e1 = epoch_masks(0, 1)
+    assert e0.shape == e1.shape == (4, 16, 32, 32, 1)
+    assert not torch.equal(e0, e1)                     # second epoch: new masks
+    r1 = epoch_masks(1, 1)[0]
+    assert not torch.equal(e0, r1)                     # other rank, same torch seed: different masks
+
+
+def test_eval_sharding_sees_every_sample_once():
+    from p2igan_bench.parallel import ShardedSampler
+    for n, world in [(10, 4), (7, 2), (3, 4), (16, 8)]:
+        seen = []
+        for r in range(world):
+            s = ShardedSampler(n, r, world, shuffle=False, even=False)
+            idx = list(s)
+            assert len(idx) == len(s)
+            seen += idx
+        assert sorted(seen) == list(range(n))
+        tr = [list(ShardedSampler(n, r, world, shuffle=True, seed=3)) for r in range(world)]
+        assert len({len(t) for t in tr}) == 1 and len(set(sum(tr, []))) == sum(map(len, tr))     # training shards: equal, disjoint

@@ -554,3 +554,48 @@ def test_weight_pack_unpack_batched_match_per_layer(ops):
     got = ops.weight_unpack_grad_batched(dwps, ws, ws, sig, us, vs)
     for r, g_ in zip(ref, got):
         assert rel_err(g_.cpu().numpy(), r.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("C,S", [(64, 128), (128, 64), (256, 32), (512, 16)], ids=["L0_64@128", "L1_128@64", "L2_256@32", "L3_512@16"])
+def test_bf16_split_kernels_hold_fp32_accuracy_vs_float64(ops, monkeypatch, C, S):
+    """The "dtype f32" claim of the bf16-split kernels (conv_x6c.hip forward / data gradient, wgrad_x6.hip weight gradient) against a
+    FLOAT64 truth, on the four generator level shapes: widening the arithmetic pipe from one f32 MFMA to six bf16 MFMA products must
+    not cost accuracy.  Bound: error relative to max-abs < 5e-6 and at most 2x the f32-MFMA engine's own error on the same data."""
+    import ctypes
+    B = 2
+    spec = ops.ConvSpec(C, C, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    g = torch.Generator().manual_seed(100 + C)
+    x = torch.randn(B, C, S, S, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    dy = torch.randn(B, C, S, S, generator=g)
+    x64, w64, dy64 = x.double().requires_grad_(True), w.double().requires_grad_(True), dy.double()
+    y64 = F.conv2d(x64, w64, None, 1, 1)
+    y64.backward(dy64)
+    xg, dyg = x.cuda(), dy.cuda()
+    wp_f, wp_d = ops.weight_pack(w.reshape(C, C, 9).cuda())
+    wplan = (ctypes.c_int * 4)()
+    err = {}
+    old = ops.CONV_ENGINE
+    try:
+        for eng in ("f32", "auto"):
+            ops.CONV_ENGINE = eng
+            if eng == "f32":
+                monkeypatch.setenv("P2I_WGRAD_X6", "0")
+            else:
+                monkeypatch.delenv("P2I_WGRAD_X6", raising=False)
+                monkeypatch.setenv("P2I_X6C_MIN_WG", "1")
+            y = ops.conv_fwd(spec, xg, wp_f)
+            assert (_last_plan(ops)[5] == 7) == (eng == "auto"), (eng, _last_plan(ops))
+            dx = ops.conv_dgrad(spec, dyg, wp_d, tuple(xg.shape))
+            assert (_last_plan(ops)[5] == 7) == (eng == "auto"), (eng, _last_plan(ops))
+            dwp, _ = ops.conv_wgrad(spec, xg, dyg)
+            ops._hip.load().p2i_wgrad_last_plan(wplan)
+            assert (wplan[0] == 3) == (eng == "auto"), (eng, tuple(wplan))
+            dw = ops.weight_unpack_grad(dwp, w.reshape(C, C, 9).cuda()).reshape(C, C, 3, 3)
+            err[eng] = (rel_err(y.double().cpu().numpy(), y64.detach().numpy()), rel_err(dx.double().cpu().numpy(), x64.grad.numpy()),
+                        rel_err(dw.double().cpu().numpy(), w64.grad.numpy()))
+    finally:
+        ops.CONV_ENGINE = old
+    for i, kind in enumerate(("fwd", "dgrad", "wgrad")):
+        assert err["auto"][i] < 5e-6, (kind, err)
+        assert err["auto"][i] <= 2.0 * err["f32"][i] + 2e-7, (kind, err)
