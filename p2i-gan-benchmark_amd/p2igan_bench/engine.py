@@ -15,7 +15,7 @@ import torch.nn as nn
 from . import ops
 from .models import p2igan as net_fns
 from .modules.losses import ReconstructionLoss, discriminator_loss, generator_adv_loss
-from .parallel import FlatParams, allreduce_mean_, broadcast_module_state
+from .parallel import BucketedAllReduce, FlatParams, allreduce_mean_, broadcast_module_state
 
 
 class FusedAdam:
@@ -86,12 +86,30 @@ class TrainEngine:
         self.world = dist.get_world_size() if self.distributed else 1
         if self.distributed:
             self.broadcast_state()
+        # data-parallel exchange of the generator's gradients: per-Decoder-level buckets launched from inside the backward
+        # (P2I_DP_OVERLAP=0: one flat all-reduce after the whole backward, the round-2 behaviour)
+        self.dp_overlap = os.environ.get("P2I_DP_OVERLAP", "1") != "0"
+        self._level_ranges = None
 
     def broadcast_state(self):
         """Rank 0's weights, spectral-norm u/v and frozen tensors to every rank, once."""
         broadcast_module_state(self.G, self.gp)
         if self.D is not None:
             broadcast_module_state(self.D, self.dp)
+
+    def level_range(self, lvl: int):
+        """[lo, hi) of Decoder[lvl]'s trainable parameters in the flat gradient buffer (contiguous: construction order)."""
+        if self._level_ranges is None:
+            base, rngs = self.gp.grad.data_ptr(), []
+            for blk in self.G.Decoder:
+                ps = [p for p in blk.parameters() if p.requires_grad]
+                lo = min((p.grad.data_ptr() - base) // 4 for p in ps)
+                hi = max((p.grad.data_ptr() - base) // 4 + p.numel() for p in ps)
+                if hi - lo != sum(p.numel() for p in ps):
+                    raise RuntimeError("Decoder level is not one contiguous slice of the flat gradient buffer")
+                rngs.append((int(lo), int(hi)))
+            self._level_ranges = rngs
+        return self._level_ranges[lvl]
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
     def capture(self, frames, masked, masks, warmup: int = 3):
@@ -124,18 +142,42 @@ class TrainEngine:
                 o.step_count -= 1
         return warmup
 
+    # Automatic graph replay: a step of ~800 dependent launches costs the host ~9 ms to enqueue, whatever the batch; when the GPU
+    # needs less than that (small B x H x W: configs[4]'s per-GPU batch, B=1..4 at 128x128) the step is launch-bound and the
+    # replay of ONE captured hipGraph removes the bound.  Single process, direct engine, same input shapes for AUTO_GRAPH_AFTER
+    # consecutive eager steps; P2I_AUTO_GRAPH=0 disables, =1 forces it for every size.  Larger batches keep eager launches (the
+    # chip is saturated either way and the capture pins the step's working set).
+    AUTO_GRAPH_AFTER = 3
+    AUTO_GRAPH_MAX_VOXELS = 4 * 16 * 128 * 128
+
+    def _auto_graph_wanted(self, frames) -> bool:
+        import os
+        mode = os.environ.get("P2I_AUTO_GRAPH", "auto")
+        if mode == "0" or self.distributed or not self.direct or self.phase_marks is not None or ops.PROFILE is not None:
+            return False
+        return mode == "1" or frames.numel() <= self.AUTO_GRAPH_MAX_VOXELS
+
     def train_step(self, frames, masked, masks) -> Dict[str, torch.Tensor]:
         """One iteration of train.py:240-326.  Returns 0-dim DEVICE tensors (no host sync here)."""
         if getattr(self, "_graph", None) is not None:
-            for dst, src in zip(self._static_in, (frames, masked, masks)):
-                if dst.data_ptr() != src.data_ptr():
-                    dst.copy_(src)
-            self._graph.replay()
-            for o in (self.opt_g, self.opt_d):
-                if o is not None:
-                    o.step_count += 1
-            self.G.invalidate_weight_cache() if hasattr(self.G, "invalidate_weight_cache") else None
-            return self._static_out
+            if tuple(frames.shape) == tuple(self._static_in[0].shape):
+                for dst, src in zip(self._static_in, (frames, masked, masks)):
+                    if dst.data_ptr() != src.data_ptr():
+                        dst.copy_(src)
+                self._graph.replay()
+                for o in (self.opt_g, self.opt_d):
+                    if o is not None:
+                        o.step_count += 1
+                self.G.invalidate_weight_cache() if hasattr(self.G, "invalidate_weight_cache") else None
+                return self._static_out
+            return self._step_impl(frames, masked, masks)        # another shape (a tail batch): eager, same device-side Adam counters
+        if self._auto_graph_wanted(frames):
+            shp = tuple(frames.shape)
+            self._same_shape_steps = getattr(self, "_same_shape_steps", 0) + 1 if getattr(self, "_last_shape", None) == shp else 0
+            self._last_shape = shp
+            if self._same_shape_steps >= self.AUTO_GRAPH_AFTER:
+                self.capture(frames, masked, masks, warmup=0)
+                return self.train_step(frames, masked, masks)
         return self._step_impl(frames, masked, masks)
 
     def _mark(self):
@@ -183,10 +225,16 @@ class TrainEngine:
                 loss_g = ops.add2(out3[2:3], adv)
                 out.update(loss_d=loss_d.reshape(()), adv=adv.reshape(()), logits_real=lr_, logits_fake=lf)
             self.gp.zero_grad()
-            net_fns.generator_backward(G, S, dgen, inplace=True)
-            del S
-            if self.distributed:
-                _allreduce_mean(self.gp.grad, self.world)
+            if self.distributed and self.dp_overlap:
+                bk = BucketedAllReduce(self.gp.grad, self.world, (lambda t, a: ops.axpy_(t, t, a - 1.0)) if self.gp.grad.is_cuda else None)
+                net_fns.generator_backward(G, S, dgen, inplace=True, on_level_done=lambda lvl: bk.launch(*self.level_range(lvl)))
+                del S
+                bk.finish()
+            else:
+                net_fns.generator_backward(G, S, dgen, inplace=True)
+                del S
+                if self.distributed:
+                    _allreduce_mean(self.gp.grad, self.world)
             self.opt_g.step()
             out.update(loss_g=loss_g.reshape(()), preds=preds)
             self._mark()

@@ -283,10 +283,12 @@ def generator_forward(net: "P2IGenerator", masked_frames, masks, need_grad: bool
     return z.view(b, t, c, h, w), S
 
 
-def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False):
+def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False, on_level_done=None):
     """Hand-sequenced backward of generator_forward.  inplace=False: returns {id(parameter): gradient}.  inplace=True (TrainEngine:
     every .grad is a zeroed view of the flat gradient buffer and every parameter is used once): gradients are written straight
-    into the .grad views -- no AccumulateGrad add, no copy -- and an empty dict is returned."""
+    into the .grad views -- no AccumulateGrad add, no copy -- and an empty dict is returned.  on_level_done(lvl) (inplace only) is
+    called on the launch stream right after the gradients of Decoder[lvl] are complete (data-parallel runs start that level's
+    all-reduce there, beside the rest of the backward)."""
     b, t, h, w = S["shape"]
     BASE_CH = net.base
     grads = {}
@@ -338,6 +340,8 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False):
         if not inplace:
             for (_, cv), dW_, dD_ in zip(pend, dWs, dDs):
                 grads[id(cv.W)], grads[id(cv.D)] = dW_, dD_
+        elif on_level_done is not None:
+            on_level_done(lvl)
         return dh
 
     def uppos_bwd(i, dr):

@@ -74,6 +74,40 @@ def allreduce_mean_(buf: torch.Tensor, world: int, scale_fn=None):
         buf.mul_(1.0 / world)
 
 
+class BucketedAllReduce:
+    """The flat gradient buffer exchanged as contiguous BUCKETS, each launched asynchronously the moment the backward pass has
+    finished writing it, so that the exchange of the early buckets runs beside the rest of the backward (the generator's backward
+    completes Decoder level 0 first and level 3 -- 74 % of the bytes -- last).  launch(lo, hi) is called from the stream that wrote
+    grad[lo:hi] (the collective is ordered behind everything enqueued there so far: RCCL waits on an event of the current
+    stream and runs on its own stream); finish() launches what was not covered yet, waits for every bucket and applies the 1/world
+    mean.  Two ranks: bit-identical to one flat all-reduce (a sum of two addends has no order); more ranks: equal to rounding."""
+
+    def __init__(self, grad: torch.Tensor, world: int, scale_fn=None):
+        self.grad, self.world, self.scale_fn = grad, world, scale_fn
+        self.works, self.done = [], []
+
+    def launch(self, lo: int, hi: int):
+        if hi > lo:
+            self.works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            self.done.append((lo, hi))
+
+    def finish(self):
+        pos = 0
+        for lo, hi in sorted(self.done):            # the gaps between the launched buckets
+            if lo > pos:
+                self.launch(pos, lo)
+            pos = max(pos, hi)
+        if pos < self.grad.numel():
+            self.launch(pos, self.grad.numel())
+        for w in self.works:
+            w.wait()                                # the current stream waits for the collective's stream
+        self.works, self.done = [], []
+        if self.scale_fn is not None:
+            self.scale_fn(self.grad, 1.0 / self.world)
+        else:
+            self.grad.mul_(1.0 / self.world)
+
+
 def broadcast_module_state(module: nn.Module, flat: Optional[FlatParams] = None, src: int = 0):
     """Rank `src`'s weights, buffers (spectral-norm u/v) and frozen tensors to every rank, once: afterwards
     the deterministic updates keep ranks bit-identical."""

@@ -349,9 +349,21 @@ def _dp_worker(rank, world, port, out):
     eng = TrainEngine(G, D, cfg, distributed=True)
     frames, masked, masks = [t.to(dev) for t in _batch32()]
     sl = slice(rank, rank + 1)
+    assert eng.dp_overlap                       # default: per-level buckets launched from inside the generator's backward
     for _ in range(2):
         eng.train_step(frames[sl].contiguous(), masked[sl].contiguous(), masks[sl].contiguous())
-    torch.save({"g": eng.gp.flat.cpu(), "d": eng.dp.flat.cpu()}, os.path.join(out, f"r{rank}.pt"))
+    res = {"g": eng.gp.flat.cpu(), "d": eng.dp.flat.cpu()}
+    # the bucketed exchange against the single flat all-reduce, one step from the same state (equal up to the float atomics
+    # of the few small reductions of a backward pass)
+    grads = []
+    for overlap in (True, False):
+        _, G2, D2 = _build(dev)
+        e2 = TrainEngine(G2, D2, cfg, distributed=True)
+        e2.dp_overlap = overlap
+        e2.train_step(frames[sl].contiguous(), masked[sl].contiguous(), masks[sl].contiguous())
+        grads.append(e2.gp.grad.cpu().clone())
+    res["bucket_vs_flat"] = float((grads[0] - grads[1]).abs().max() / grads[1].abs().max())
+    torch.save(res, os.path.join(out, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -366,6 +378,7 @@ def test_two_rank_data_parallel_matches_single_process(dev, tmp_path):
     mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["d"], r1["d"])          # ranks stay bit-identical
+    assert r0["bucket_vs_flat"] < 1e-6 and r1["bucket_vs_flat"] < 1e-6, (r0["bucket_vs_flat"], r1["bucket_vs_flat"])
     cfg, G, D = _build(dev)
     eng = TrainEngine(G, D, cfg)
     frames, masked, masks = [t.to(dev) for t in _batch32()]

@@ -79,3 +79,31 @@ def test_flat_params_views_and_grad_accumulation():
     assert float(fp.grad.abs().sum()) > 0                            # autograd accumulated INTO the flat buffer
     m.load_state_dict({k: v + 1 for k, v in m.state_dict().items()})  # in-place load keeps the views
     assert torch.equal(fp.flat[:12 * 16].view(16, 12), m[0].weight.data)
+
+
+def _bucket_worker(rank, world, port, out):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "p2i-gan-benchmark_amd"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from p2igan_bench import parallel
+    parallel.init_distributed("gloo")
+    g = torch.Generator().manual_seed(100 + rank)
+    grad = torch.randn(10_000, generator=g)
+    flat = grad.clone()
+    parallel.allreduce_mean_(flat, world)
+    bk = parallel.BucketedAllReduce(grad, world)
+    bk.launch(4000, 7000)                   # buckets become ready out of order, with gaps between them
+    bk.launch(100, 900)
+    bk.finish()                             # launches [0,100), [900,4000), [7000,10000), waits, scales
+    torch.save({"flat": flat, "bucketed": grad}, os.path.join(out, f"b{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_bucketed_allreduce_is_bit_identical_to_flat(tmp_path):
+    """The overlapped per-level exchange of the generator's gradients (parallel.BucketedAllReduce, engine.py) must give exactly
+    what the single flat all-reduce gives: with two ranks every element is a sum of two addends, so there is no order to differ in."""
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    mp.spawn(_bucket_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "b0.pt"), torch.load(tmp_path / "b1.pt")
+    assert torch.equal(r0["flat"], r0["bucketed"]) and torch.equal(r1["flat"], r1["bucketed"])
+    assert torch.equal(r0["bucketed"], r1["bucketed"])
