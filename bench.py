@@ -206,30 +206,33 @@ def loader_leg(eng, dev, B, steps, warmup, workers):
         root = os.path.join(tmp, "train.zarr")
         nwin = write_train_zarr(root, n_events=64, frames_per_event=30, h=H, w=W, window=T, stride=2)
         cfg = dict(make_cfg(), data={"train": {"data_root": root, "w": W, "h": H, "sample_length": T, "mask": {"type": "sti", "block_sizes": [10]}}})
-        cfg["train"] = dict(cfg["train"], batch_size=B, num_workers=workers, device_assemble=True, pin_memory=True, persistent_workers=workers > 0)
+        cfg["train"] = dict(cfg["train"], batch_size=B, num_workers=workers, device_assemble=True, pin_memory=False, persistent_workers=workers > 0)
         import random
         import numpy as np
         random.seed(cfg["seed"])
         np.random.seed(cfg["seed"])
         loader = P2IDataModule(cfg).train_dataloader()
 
-        def batches():
+        from p2igan_bench.data.prefetch import DevicePrefetcher
+
+        def epochs(src):
             while True:
-                for b in loader:
+                for b in src:
                     if b[0].shape[0] == B:
                         yield b
 
-        it = batches()
+        it = epochs(loader)
         next(it)                                          # first batch: worker start-up, page cache
         n_alone = max(8, min(4 * steps, 64))
         t0 = time.perf_counter()
         for _ in range(n_alone):
             next(it)
         host_sps = n_alone * B / (time.perf_counter() - t0)
+        del it
+        it = epochs(DevicePrefetcher(loader, dev))        # what scripts/train.py iterates: fp32 triples already on the device
 
         def step():
-            fr, mk = next(it)
-            eng.train_step(*ops.assemble_batch(fr.to(dev, non_blocking=True).contiguous(), mk.to(dev, non_blocking=True).contiguous()))
+            eng.train_step(*next(it))
 
         for _ in range(max(1, warmup)):
             step()
@@ -243,7 +246,8 @@ def loader_leg(eng, dev, B, steps, warmup, workers):
         return {"step_ms_with_loader": round(ms, 3), "frames_per_s_with_loader": round(B * T / ms * 1e3, 1),
                 "loader_samples_per_s": round(host_sps, 1), "loader_needs_samples_per_s": None,
                 "loader": {"store": "synthetic train.zarr, %d windows of %d frames from 64 events (zarr_lite, uncompressed uint8 chunks (20,128,128))" % (nwin, T),
-                           "num_workers": workers, "device_assemble": True, "mask": "sti block 10", "steps": steps}}
+                           "num_workers": workers, "device_assemble": True, "prefetch": "DevicePrefetcher (helper thread, pinned staging, copy stream)",
+                           "mask": "sti block 10", "steps": steps}}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -143,6 +143,7 @@ class Dataset_ZarrTrain(torch.utils.data.Dataset):
         self.events = self.z["events"]
         self.index = np.asarray(self.z["index"]["windows"][:])
         self.keys = sorted(self.events.keys())
+        self._frames = {}            # event key -> opened `frames` array (metadata parsed once, chunk cache kept: zarr_lite.Array)
         self.crop_h, self.crop_w = args["h"], args["w"]
         m = args.get("mask", {})
         self.mask_type, self.mask_file = m.get("type", "sti"), m.get("file")
@@ -154,7 +155,9 @@ class Dataset_ZarrTrain(torch.utils.data.Dataset):
 
     def __getitem__(self, idx):
         ev, t0, L = (int(x) for x in self.index[idx])
-        fr = self.events[self.keys[ev]]["frames"]
+        fr = self._frames.get(ev)
+        if fr is None:
+            fr = self._frames[ev] = self.events[self.keys[ev]]["frames"]
         T, H, W = fr.shape
         y0 = 0 if H == self.crop_h else random.randint(0, H - self.crop_h)
         x0 = 0 if W == self.crop_w else random.randint(0, W - self.crop_w)

@@ -31,15 +31,32 @@ class Array:
         self.fill = meta.get("fill_value") or 0
         self.zlib = comp is not None
         self.sep = meta.get("dimension_separator", ".")
+        # decoded chunks of a read-only array, most recently used last (a training window re-reads the same one or two chunks
+        # for every overlapping window of an event; on the GPU box an uncached window read cost 2 ms of stat / open / read)
+        self._cache: "Dict[tuple, np.ndarray]" = {}
+        self._cache_bytes = 0
+
+    CACHE_BYTES = 64 << 20       # per array
 
     def _chunk(self, idx) -> np.ndarray:
+        hit = self._cache.get(idx)
+        if hit is not None:
+            return hit
         f = os.path.join(self.path, self.sep.join(map(str, idx)) if idx else "0")
-        if not os.path.exists(f):
+        try:
+            with open(f, "rb") as fh:
+                raw = fh.read()
+        except FileNotFoundError:
             return np.full(self.chunks, self.fill, dtype=self.dtype)
-        raw = open(f, "rb").read()
         if self.zlib:
             raw = zlib.decompress(raw)
-        return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks)
+        ch = np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks)
+        if ch.nbytes <= self.CACHE_BYTES:
+            while self._cache and self._cache_bytes + ch.nbytes > self.CACHE_BYTES:
+                self._cache_bytes -= self._cache.pop(next(iter(self._cache))).nbytes
+            self._cache[idx] = ch
+            self._cache_bytes += ch.nbytes
+        return ch
 
     def __getitem__(self, key) -> np.ndarray:
         if not isinstance(key, tuple):

@@ -142,20 +142,18 @@ class TrainEngine:
                 o.step_count -= 1
         return warmup
 
-    # Automatic graph replay: a step of ~800 dependent launches costs the host ~9 ms to enqueue, whatever the batch; when the GPU
-    # needs less than that (small B x H x W: configs[4]'s per-GPU batch, B=1..4 at 128x128) the step is launch-bound and the
-    # replay of ONE captured hipGraph removes the bound.  Single process, direct engine, same input shapes for AUTO_GRAPH_AFTER
-    # consecutive eager steps; P2I_AUTO_GRAPH=0 disables, =1 forces it for every size.  Larger batches keep eager launches (the
-    # chip is saturated either way and the capture pins the step's working set).
+    # Automatic graph replay (opt-in: P2I_AUTO_GRAPH=1).  Measured in round 3 (gpurun_out/r03a/loader_probe.log, profiles/README.md):
+    # hipGraphLaunch of the ~800-node step costs the host 6-10 ms, i.e. as much as enqueueing the launches one by one (B=1: 8.97 ms
+    # replayed vs 8.21 ms eager; B=8: 15.8 vs 15.6), so replay does not lift the launch bound of small steps on ROCm 7.2 and is
+    # not the default.  With P2I_AUTO_GRAPH=1 the engine captures by itself once the same input shapes have repeated
+    # AUTO_GRAPH_AFTER times (single process, direct engine); a batch of another shape (tail batch) then runs eagerly.
     AUTO_GRAPH_AFTER = 3
-    AUTO_GRAPH_MAX_VOXELS = 4 * 16 * 128 * 128
 
     def _auto_graph_wanted(self, frames) -> bool:
         import os
-        mode = os.environ.get("P2I_AUTO_GRAPH", "auto")
-        if mode == "0" or self.distributed or not self.direct or self.phase_marks is not None or ops.PROFILE is not None:
+        if os.environ.get("P2I_AUTO_GRAPH", "0") != "1":
             return False
-        return mode == "1" or frames.numel() <= self.AUTO_GRAPH_MAX_VOXELS
+        return not (self.distributed or not self.direct or self.phase_marks is not None or ops.PROFILE is not None)
 
     def train_step(self, frames, masked, masks) -> Dict[str, torch.Tensor]:
         """One iteration of train.py:240-326.  Returns 0-dim DEVICE tensors (no host sync here)."""

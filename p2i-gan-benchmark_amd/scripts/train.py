@@ -20,6 +20,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 from p2igan_bench import ops, parallel  # noqa: E402
 from p2igan_bench.data.dataloader import P2IDataModule  # noqa: E402
+from p2igan_bench.data.prefetch import DevicePrefetcher  # noqa: E402
 from p2igan_bench.engine import TrainEngine  # noqa: E402
 from p2igan_bench.models import build_discriminator, build_generator  # noqa: E402
 
@@ -156,8 +157,12 @@ class Trainer:
             if hasattr(self.train_loader.sampler, "set_epoch"):
                 self.train_loader.sampler.set_epoch(epoch)
             run, steps = None, 0
-            for batch in self.train_loader:
-                out = self.engine.train_step(*self._batch(batch))
+            # batches arrive on the device one step ahead (helper thread + copy stream: data/prefetch.py); train.prefetch=false
+            # keeps the reference's in-line hand-over (train.py:468-473)
+            feed = DevicePrefetcher(self.train_loader, self.device) if self.cfg.get("train", {}).get("prefetch", True) else \
+                (self._batch(b) for b in self.train_loader)
+            for batch in feed:
+                out = self.engine.train_step(*batch)
                 # stays on the device; cloned because a graph-replayed step returns the same output tensors every call
                 run = out["loss_g"].clone() if run is None else run + out["loss_g"]
                 steps += 1

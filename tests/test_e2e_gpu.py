@@ -706,3 +706,30 @@ def test_zarr_windows_two_rank_data_parallel_matches_single_process(dev, tmp_pat
         diff = (flat.cpu() - r0[key]).abs()
         assert float((diff > 5e-5).float().mean()) < 2e-3, key
         assert float(diff.max()) <= 4.1e-4, key
+
+
+def test_auto_graph_replay_for_launch_bound_steps(dev, monkeypatch):
+    """With P2I_AUTO_GRAPH=1 TrainEngine captures the step by itself once it has repeated AUTO_GRAPH_AFTER times with the same
+    shapes, keeps following the eager engine (same tolerance reasoning as test_graph_replay_matches_eager_steps, two steps later),
+    and runs a batch of another shape eagerly without disturbing the captured graph or the Adam step counters."""
+    from p2igan_bench.engine import TrainEngine
+    frames, masked, masks = [t.to(dev) for t in _batch32()]
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("P2I_AUTO_GRAPH", mode)
+        cfg, G, D = _build(dev)
+        eng = TrainEngine(G, D, cfg)
+        for i in range(5):
+            r = eng.train_step(frames, masked, masks)
+            assert (getattr(eng, "_graph", None) is not None) == (mode == "1" and i >= TrainEngine.AUTO_GRAPH_AFTER), (mode, i)
+        runs[mode] = {k: float(r[k]) for k in ("loss_g", "loss_d", "rec")}
+        assert eng.opt_g.step_count == 5 and eng.opt_d.step_count == 5
+        if mode == "1":
+            assert int(eng.opt_g.step_dev) == 5
+            r1 = eng.train_step(frames[:1].contiguous(), masked[:1].contiguous(), masks[:1].contiguous())     # tail batch: eager
+            assert r1["preds"].shape[0] == 1 and bool(torch.isfinite(r1["loss_g"]))
+            assert eng.opt_g.step_count == 6 and int(eng.opt_g.step_dev) == 6
+            r2 = eng.train_step(frames, masked, masks)                                                          # replay again
+            assert r2["preds"].shape[0] == 2 and int(eng.opt_g.step_dev) == 7
+    for k in runs["0"]:
+        assert abs(runs["0"][k] - runs["1"][k]) <= 1e-2 * abs(runs["0"][k]), (k, runs)

@@ -1,5 +1,6 @@
 """Full train steps at the other BASELINE.json configurations' per-GPU shapes (sanity: ms/step, frames/s, finite losses, peak memory).
-usage: python tools/sanity_cfgs.py"""
+usage: python tools/sanity_cfgs.py            (the table below)
+       python tools/sanity_cfgs.py B H W [T]   (one case, e.g. under rocprofv3)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "p2i-gan-benchmark_amd"))
@@ -16,22 +17,29 @@ def run(B, H, W, T=16, steps=3, note=""):
     torch.manual_seed(0)
     G = build_generator(cfg).to(dev); D = build_discriminator(cfg).to(dev); eng = TrainEngine(G, D, cfg)
     f, k, m = [t.to(dev) for t in seeded.synthetic_batch(B, T, H, W, seeded.gauge_mask(H, W, 79 * H * W // 16384))]
-    for _ in range(2):
+    for _ in range(5):                       # (past TrainEngine.AUTO_GRAPH_AFTER when P2I_AUTO_GRAPH=1)
         out = eng.train_step(f, k, m)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
         out = eng.train_step(f, k, m)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     print(f"B={B} T={T} {H}x{W} {note}: {dt * 1e3:.1f} ms/step {B * T / dt:.0f} frames/s loss_g={float(out['loss_g']):.4f} "
-          f"loss_d={float(out['loss_d']):.4f} finite={bool(torch.isfinite(out['preds']).all())} mem={torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+          f"loss_d={float(out['loss_d']):.4f} launch={'graph' if getattr(eng, '_graph', None) is not None else 'eager'} finite={bool(torch.isfinite(out['preds']).all())} mem={torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
     del eng, G, D
     torch.cuda.empty_cache()
 
 
+if len(sys.argv) >= 4:
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), T=int(sys.argv[4]) if len(sys.argv) > 4 else 16, note="(command line)")
+    sys.exit(0)
 run(8, 128, 128, note="configs[1]/[2] per-GPU shape")
 run(32, 128, 128, note="B=32 (north_star stack target batch)")
 run(4, 256, 256, note="configs[3] per-GPU shape (B=16 over 4 GPUs)")
 run(16, 256, 256, note="configs[3] on one GPU")
 run(4, 128, 128, T=32, note="configs[4] per-GPU shape (B=32 over 8 GPUs; T=32 generalisation, parity unpinned)")
 run(1, 128, 128, note="B=1 (launch-bound)")
-run(2, 64, 96, note="non-square")
+run(2, 128, 128, note="B=2")
+run(4, 128, 128, note="B=4")
+run(2, 64, 96, note="non-square, non-power-of-two width")
+run(2, 128, 160, note="non-power-of-two width")
+run(2, 64, 64, note="small square (for comparison with 64x96)")
