@@ -453,6 +453,10 @@ extern "C" int p2i_conv_fwd(const p2i_conv_desc* d, const float* x, const float*
     const int rc = c1_fwd(d, x, wp, bias, y, act, (hipStream_t)stream);
     if (rc != 1) { g_last_plan[0] = 32; g_last_plan[1] = 64; g_last_plan[2] = 1; g_last_plan[3] = 2; g_last_plan[4] = 27; g_last_plan[5] = 1; return rc; }
   }
+  if (d->Cout == 1 && residual == nullptr) {                                  // single-channel output: bandwidth kernel (conv_c1.hip)
+    const int rc = o1_fwd(d, x, wp, bias, y, act, (hipStream_t)stream);
+    if (rc != 1) { g_last_plan[0] = 1; g_last_plan[1] = 64; g_last_plan[2] = 8; g_last_plan[3] = 1; g_last_plan[4] = 9; g_last_plan[5] = 3; return rc; }
+  }
   PatchGeom g{};
   g.src = x; g.src_y = nullptr; g.wp = wp; g.bias = bias; g.res = residual; g.dst = y; g.act_epi = act; g.act_pro = P2I_ACT_NONE;
   g.B = d->B; g.Ck = d->Cin; g.Cm = d->Cout; g.CmPad = (d->Cout + 31) / 32 * 32;
@@ -518,7 +522,10 @@ extern "C" int p2i_conv_dgrad(const p2i_conv_desc* d, const float* dy, const flo
         else if (int e = run_patch_gemm(g, cs, (hipStream_t)stream)) return e;
       }
   if (mergeable) {
-    int rc = (ncls > 1 && x6_ctx().wb == nullptr) ? run_patch_gemm_fused(g, css, ncls, g_last_plan, (hipStream_t)stream) : 1;
+    int rc = 1;
+    if (const X6Ctx& xc = x6_ctx(); xc.wb != nullptr && ncls == 4)      // bf16-split kernel with the four parity classes fused
+      rc = run_patch_gemm_x6c_fused(g, css, ncls, xc.wb, xc.ntaps_w, g_last_plan, (hipStream_t)stream);
+    if (rc == 1) rc = (ncls > 1 && x6_ctx().wb == nullptr) ? run_patch_gemm_fused(g, css, ncls, g_last_plan, (hipStream_t)stream) : 1;
     if (rc == 1) rc = ncls > 1 ? run_patch_gemm_classes(g, css, ncls, (hipStream_t)stream) : 1;
     if (rc == 1) {
       for (int q = 0; q < ncls; ++q)

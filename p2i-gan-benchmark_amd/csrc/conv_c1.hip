@@ -495,4 +495,109 @@ static int c1_wgrad_mfma(const p2i_conv_desc* d, const float* x, const float* dy
   return launch_status();
 }
 
+// ---- single-OUTPUT-channel forward (the 2-D discriminator's last layer, Conv2d(256, 1, 3, padding 1): p2igan.py:129).  One output
+// channel leaves 31 of 32 MFMA rows empty in the patch-GEMM engine (50 us for 8.4 MB of input at B = 8); this is a bandwidth
+// problem: x is read ONCE.  Workgroup = 2 output rows x 32 columns of one image, wave w = channels w, w+8, ...; a lane holds pixel
+// (row lane >> 5, column lane & 31), loads the three vertically adjacent values of its column per channel (full 128-B rows) and gets
+// the horizontal neighbours from its lane neighbours; the eight waves' partial sums meet in LDS.  Deterministic (no atomics).
+__global__ __launch_bounds__(512) void o1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                    float* __restrict__ y, int Cin, int H, int W, int nth, int ntw, int act) {
+  extern __shared__ float osm[];                      // [Cin][9] weights, then [8][64] partial sums
+  float* sw = osm;
+  float* red = osm + ((Cin * 9 + 63) & ~63);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < Cin * 9; i += 512) {
+    const int c = i / 9, tap = i - c * 9;
+    sw[i] = wp[((size_t)tap * Cin + c) * 32];         // packed [tap][c][pad32(1)], output channel 0
+  }
+  int t = blockIdx.x;
+  const int tw = t % ntw; t /= ntw;
+  const int th = t % nth;
+  const int b = t / nth;
+  const int r = lane >> 5, col = lane & 31;
+  const int h = th * 2 + r, w = tw * 32 + col;
+  const bool wide = ntw > 1;                          // wave-uniform: tile edges have neighbours in the next tile
+  const bool in_w = w < W;
+  const bool up = h - 1 >= 0 && h - 1 < H && in_w, mid = h < H && in_w, dn = h + 1 < H && in_w;
+  const int HW = H * W;
+  const float* xb = x + (size_t)b * Cin * HW + (size_t)h * W + w;
+  __syncthreads();
+  float acc = 0.f;
+  // loads of a channel are unconditional (clamped offsets, values masked afterwards) so that the loop unrolls and the loads of
+  // several channels are in flight together: a conditional load makes hipcc branch around it and wait before the next one
+  const int o_up = up ? -W : 0, o_dn = dn ? W : 0;
+  const int nc = (Cin - wave + 7) >> 3;              // channels of this wave: wave, wave + 8, ...
+  if (!wide) {
+    const bool lz = col == 0, rz = col == 31;
+    const float* xm = mid ? xb : x;                  // (a pixel of the tile outside the image reads element 0 and is masked)
+    auto tap9 = [&](int c, float v0, float v1, float v2) {
+      v0 = up ? v0 : 0.f; v1 = mid ? v1 : 0.f; v2 = dn ? v2 : 0.f;
+      float l0 = __shfl_up(v0, 1, 32), l1 = __shfl_up(v1, 1, 32), l2 = __shfl_up(v2, 1, 32);
+      float r0 = __shfl_down(v0, 1, 32), r1 = __shfl_down(v1, 1, 32), r2 = __shfl_down(v2, 1, 32);
+      l0 = lz ? 0.f : l0; l1 = lz ? 0.f : l1; l2 = lz ? 0.f : l2;
+      r0 = rz ? 0.f : r0; r1 = rz ? 0.f : r1; r2 = rz ? 0.f : r2;
+      const float* k = sw + c * 9;
+      acc += k[0] * l0 + k[1] * v0 + k[2] * r0 + k[3] * l1 + k[4] * v1 + k[5] * r1 + k[6] * l2 + k[7] * v2 + k[8] * r2;
+    };
+    // eight channels per trip, their 24 loads issued together (hipcc does not unroll this loop by itself: one channel per
+    // trip means one exposed memory latency per channel)
+    int ci = 0;
+    for (; ci + 8 <= nc; ci += 8) {
+      float v[8][3];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* xc = xm + (size_t)(wave + 8 * (ci + u)) * HW;
+        v[u][0] = xc[o_up]; v[u][1] = xc[0]; v[u][2] = xc[o_dn];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tap9(wave + 8 * (ci + u), v[u][0], v[u][1], v[u][2]);
+    }
+    for (; ci < nc; ++ci) {
+      const float* xc = xm + (size_t)(wave + 8 * ci) * HW;
+      tap9(wave + 8 * ci, xc[o_up], xc[0], xc[o_dn]);
+    }
+  } else {
+    // several column tiles: every lane reads its own left and right neighbours (columns w - 1, w + 1 of the image)
+    const bool lok = w > 0 && w - 1 < W, rok = w + 1 < W;
+    const int h_c = h < H ? h : H - 1;
+    const float* xr = x + (size_t)b * Cin * HW + (size_t)h_c * W;      // row start (clamped row)
+    const int wl = lok ? w - 1 : 0, wm = in_w ? w : 0, wr = rok ? w + 1 : 0;
+    const bool hu = h - 1 >= 0 && h - 1 < H, hm = h < H, hd = h + 1 < H;
+    const int ou = hu ? -W : 0, od = hd ? W : 0;
+#pragma unroll 2
+    for (int ci = 0; ci < nc; ++ci) {
+      const int c = wave + 8 * ci;
+      const float* xc = xr + (size_t)c * HW;
+      const float* k = sw + c * 9;
+      const float a0 = xc[ou + wl], a1 = xc[ou + wm], a2 = xc[ou + wr], b0 = xc[wl], b1 = xc[wm], b2 = xc[wr];
+      const float c0 = xc[od + wl], c1 = xc[od + wm], c2 = xc[od + wr];
+      acc += k[0] * (hu && lok ? a0 : 0.f) + k[1] * (hu && in_w ? a1 : 0.f) + k[2] * (hu && rok ? a2 : 0.f) +
+             k[3] * (hm && lok ? b0 : 0.f) + k[4] * (hm && in_w ? b1 : 0.f) + k[5] * (hm && rok ? b2 : 0.f) +
+             k[6] * (hd && lok ? c0 : 0.f) + k[7] * (hd && in_w ? c1 : 0.f) + k[8] * (hd && rok ? c2 : 0.f);
+    }
+  }
+  red[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    float v = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += red[q * 64 + lane];
+    if (mid) y[(size_t)b * HW + (size_t)h * W + w] = act_apply(v, act);
+  }
+}
+
+// 1 = not a case of this kernel
+int o1_fwd(const p2i_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, hipStream_t s) {
+  static const int on = getenv("P2I_O1_FWD") ? atoi(getenv("P2I_O1_FWD")) : 1;
+  if (!on || d->Cout != 1 || d->kt != 1 || d->kh != 3 || d->kw != 3 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt != 0 || d->ph != 1 ||
+      d->pw != 1 || d->Ti != 1 || d->Cin < 8 || d->Cin > 2048)
+    return 1;
+  const int nth = ceil_div(d->Ho, 2), ntw = ceil_div(d->Wo, 32);
+  const long long nt = (long long)d->B * nth * ntw;
+  if (nt > 0x7fffffff) return 1;
+  const size_t lds = sizeof(float) * (size_t)(((d->Cin * 9 + 63) & ~63) + 8 * 64);
+  hipLaunchKernelGGL(o1_fwd_kernel, dim3((unsigned)nt), dim3(512), lds, s, x, wp, bias, y, d->Cin, d->Hi, d->Wi, nth, ntw, act);
+  return launch_status();
+}
+
 }  // namespace p2i

@@ -102,7 +102,9 @@ __device__ __forceinline__ void epilogue_tile16(const f32x16& acc, int o_base, i
 // half-used ones per class (WRITE_SIZE of the fused strided dgrad was 1.6x its algorithmic bytes).  pos_off: class pW=0, even.
 __device__ __forceinline__ void epilogue_pair16(const f32x16& acc0, const f32x16& acc1, int o_base, int lhi, int Cm, bool pv, size_t pos_off,
                                                 size_t chan_stride, const float* __restrict__ res, const float* __restrict__ mask_y,
-                                                int mask_act, float* __restrict__ dst) {
+                                                int mask_act, float* __restrict__ dst, bool atomic_out = false) {
+  // atomic_out: both values are ADDED to a pre-zeroed destination (split-K partial sums: res rides with one split only, the mask
+  // factor distributes over the sum)
   typedef float f32x2e __attribute__((ext_vector_type(2)));
   // batches of 4 (8 floats in flight per tensor): the <32,128,1,*,4> instances must stay below 256 VGPRs to keep two workgroups per CU
 #pragma unroll
@@ -132,7 +134,10 @@ __device__ __forceinline__ void epilogue_pair16(const f32x16& acc0, const f32x16
       v[0] = acc0[r]; v[1] = acc1[r];
       if (res) { v[0] += rv[k][0]; v[1] += rv[k][1]; }
       if (mask_y) { v[0] = act_grad(v[0], mv[k][0], mask_act); v[1] = act_grad(v[1], mv[k][1], mask_act); }
-      if (ok[k]) *reinterpret_cast<f32x2e*>(dst + di[k]) = v;
+      if (ok[k]) {
+        if (atomic_out) { atomicAdd(dst + di[k], v[0]); atomicAdd(dst + di[k] + 1, v[1]); }
+        else *reinterpret_cast<f32x2e*>(dst + di[k]) = v;
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -237,6 +242,8 @@ X6Ctx& x6_ctx();
 
 // 3x3 stride-1 2-D layers on the bf16 matrix pipe, chunk/tap-row pipeline (conv_x6c.hip); returns 1 when it does not apply
 int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s, bool dry = false);
+// data gradient of a 3x3(x3) stride-(1,2,2) pad-1 convolution: the four input-parity classes in one workgroup, bf16 matrix pipe
+int run_patch_gemm_x6c_fused(PatchGeom g, const ClassSpec* css, int ncls, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s, bool dry = false);
 bool x6c_would_take(const p2i_conv_desc* d, bool dgrad, int act_epi);
 
 // strided dgrad with the parity classes fused in one workgroup (conv_fused.hip); returns 1 when it does not apply
@@ -248,5 +255,7 @@ int c1_dgrad(const p2i_conv_desc* d, const float* dy, const float* wp_d, const f
 int c1_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* dbias, hipStream_t s);
 // forward of the same layer; returns 1 when the shape is not the (3x3x3, stride (1,2,2), pad 1) one
 int c1_fwd(const p2i_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, hipStream_t s);
+// single-output-channel 3x3 stride-1 2-D forward (bandwidth-bound; conv_c1.hip); returns 1 when the shape is not that one
+int o1_fwd(const p2i_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, hipStream_t s);
 
 }  // namespace p2i

@@ -94,7 +94,13 @@ struct X6cGeom {
   int sT, nT, mT, oT, pT, ns, sdt0, sdt1, sdt2, swt0, swt1, swt2;
   int tap_off[9];
   int tap_w[9];
+  int fused_atomic;     // FUSED kernels with split-K: the class pairs are ADDED to a zeroed destination
 };
+
+// FUSED (data gradient of a stride-(.,2,2) 3x3 convolution: conv_fused.hip on the bf16 matrix pipe): the nine taps of a chunk belong
+// to the FOUR input-parity classes (pH, pW) of the destination -- slot s feeds accumulator class X6C_CLS[s] = 2 pH + pW -- and all
+// read ONE (jh+1) x (jw+1) patch of dy; the epilogue stores the pW pairs as float2 (rows 2 gh + pH, columns 2 gw, 2 gw + 1).
+__device__ constexpr int X6C_CLS[9] = {3, 3, 3, 3, 2, 2, 1, 1, 0};
 
 // Tile variants <NW waves, TM 32-channel tiles per wave>: a workgroup computes (32 TM) channels x (32 NW) positions, wave = 32 TM
 // channels x 32 positions.  <8,2> (64 x 256) is the efficient one (0.75 operand reads per MFMA); <8,1> (32 x 256) gives the
@@ -119,8 +125,9 @@ __device__ __forceinline__ void x6c_wait_vm(int n) {
 #undef P2I_WC
 }
 
-template <int NW, int TM>
+template <int NW, int TM, bool FUSED = false>
 __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g) {
+  constexpr int NCLS = FUSED ? 4 : 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef P2I_STAMP
   unsigned long long st_entry, st_prev, st_wait = 0, st_bar = 0, st_issue = 0, st_mfma = 0, st_loop0;
@@ -171,11 +178,13 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
 #pragma unroll
   for (int t = 0; t < 9; ++t) toff[t] = g.tap_off[t];
 
-  f32x16 acc[TM];
+  f32x16 acc[NCLS][TM];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int q = 0; q < NCLS; ++q)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][i][r] = 0.f;
 
   const v4i32 rs_w = make_rsrc(g.wb, g.wb_bytes);
   const unsigned wbuf_la = lds_base(smem) + 4u * ptab_sz;
@@ -306,13 +315,14 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
       Bv[buf][p] = pbp[p * 2 * CSl + to];
     }
   };
-  auto mfma_tap = [&](int buf) {
+  auto mfma_tap = [&](int buf, int slot) {              // slot = tap index inside the chunk (a constant after unrolling)
+    const int cl = FUSED ? X6C_CLS[slot] : 0;
 #pragma unroll
     for (int q = 0; q < 6; ++q)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, A[buf][i][PA[q]]), __builtin_bit_cast(bf16x8c, Bv[buf][PB[q]]),
-                                                         acc[i], 0, 0, 0);
+        acc[cl][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, A[buf][i][PA[q]]), __builtin_bit_cast(bf16x8c, Bv[buf][PB[q]]),
+                                                             acc[cl][i], 0, 0, 0);
   };
   auto ilv = [&]() {                                   // a tap's MFMAs with the next tap's operand reads in their gaps
     constexpr int NR = 3 * TM + 3, NM = 6 * TM;
@@ -347,11 +357,11 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
       const u32x4c* wsl = wlane + (s % RING) * WST;
       __builtin_amdgcn_sched_barrier(0);
       load_tap(wsl, pb, 3 * b + 1, 1);
-      mfma_tap(0);
+      mfma_tap(0, 3 * b);
       ilv();
       __builtin_amdgcn_sched_barrier(0);
       load_tap(wsl, pb, 3 * b + 2, 2);
-      mfma_tap(1);
+      mfma_tap(1, 3 * b + 1);
       ilv();
       __builtin_amdgcn_sched_barrier(0);
       X6C_ACC(st_mfma, st_prev);
@@ -373,7 +383,7 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
       __builtin_amdgcn_s_barrier();
       X6C_ACC(st_bar, st_prev);
       if (s + 1 < nst) load_tap(wlane + ((s + 1) % RING) * WST, b == 2 ? pbn : pb, b == 2 ? 0 : 3 * b + 3, 0);
-      mfma_tap(2);
+      mfma_tap(2, 3 * b + 2);
       ilv();
       __builtin_amdgcn_sched_barrier(0);
       X6C_ACC(st_mfma, st_prev);
@@ -388,14 +398,25 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
   const bool pvld = gn < nimg && gh < g.nH && gw < g.nW;
   const int dHW = g.dT * g.dH * g.dW;                                   // destination channel stride
   const int gb_ = gn / g.nT, glt = gn - gb_ * g.nT;
-  const size_t pos = (size_t)gb_ * g.Cm * dHW + (size_t)(glt * g.oT + g.pT) * g.dH * g.dW + (size_t)gh * g.dW + gw;
+  if constexpr (FUSED) {
+    // class (pH, pW) of position (gh, gw) is destination pixel (2 gh + pH, 2 gw + pW): the pW pair is adjacent -> float2
+    const size_t pos0 = (size_t)gb_ * g.Cm * dHW + (size_t)(glt * g.oT + g.pT) * g.dH * g.dW + (size_t)(2 * gh) * g.dW + 2 * gw;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-    if (g.ksplit > 1)       // partial sum: bias / residual ride with split 0, the mask factor (0/1 for relu') distributes over the sum
-      epilogue_tile16(acc[i], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, blockIdx.z ? nullptr : g.bias, P2I_ACT_NONE,
-                      blockIdx.z ? nullptr : g.res, g.mask_y, g.mask_act, g.dst, true);
-    else
-      epilogue_tile16(acc[i], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, g.bias, g.act_epi, g.res, g.mask_y, g.mask_act, g.dst);
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        epilogue_pair16(acc[2 * ph][i], acc[2 * ph + 1][i], o0 + i * 32, lhi, g.Cm, pvld, pos0 + (size_t)ph * g.dW, (size_t)dHW,
+                        (g.fused_atomic && blockIdx.z) ? nullptr : g.res, g.mask_y, g.mask_act, g.dst, g.fused_atomic != 0);
+  } else {
+    const size_t pos = (size_t)gb_ * g.Cm * dHW + (size_t)(glt * g.oT + g.pT) * g.dH * g.dW + (size_t)gh * g.dW + gw;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      if (g.ksplit > 1)       // partial sum: bias / residual ride with split 0, the mask factor (0/1 for relu') distributes over the sum
+        epilogue_tile16(acc[0][i], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, blockIdx.z ? nullptr : g.bias, P2I_ACT_NONE,
+                        blockIdx.z ? nullptr : g.res, g.mask_y, g.mask_act, g.dst, true);
+      else
+        epilogue_tile16(acc[0][i], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, g.bias, g.act_epi, g.res, g.mask_y, g.mask_act, g.dst);
+  }
 #ifdef P2I_STAMP
   if (p2i_stamp_buf && lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -430,6 +451,7 @@ static X6cPick x6c_pick(int B, int nH, int nW, int Cm, int Ck, bool linear_epi) 
       const int v = (ksplit_on == 2 ? order_b : order_a)[cand][0], pass = (ksplit_on == 2 ? order_b : order_a)[cand][1];
       const X6cVariant& t = kX6cVariants[v];
       if (forced && forced != t.NW * 10 + t.TM) continue;
+      if (t.TM == 2 && Cm <= 32 && !forced) continue;      // half of a 64-channel tile would be padding (16 -> 64 layers' data gradient)
       if (pass == 1 && ((ksplit_on != 2 && t.TM != 1) || !ksplit_on || !linear_epi || ((Ck >> 4) & 1) || forced)) continue;
       int jb, jt, jh, jw;
       pick_tile_dims(32 * t.NW, B, 1, nH, nW, jb, jt, jh, jw);
@@ -445,6 +467,20 @@ static X6cPick x6c_pick(int B, int nH, int nW, int Cm, int Ck, bool linear_epi) 
 bool x6c_would_take(const p2i_conv_desc* d, bool dgrad, int act_epi) {
   static const int on = getenv("P2I_CONV_X6C") ? atoi(getenv("P2I_CONV_X6C")) : 1;
   (void)act_epi;                                       // (an activation is applied by a second pass when the launch is split-K)
+  if (on && dgrad && d->sh == 2 && d->sw == 2 && d->st == 1 && d->kh == 3 && d->kw == 3 && d->ph == 1 && d->pw == 1 &&
+      ((d->kt == 1 && d->pt == 0) || (d->kt == 3 && d->pt == 1)) && (d->Cout & 15) == 0 && d->Cout >= 16 && !(d->Hi & 1) && !(d->Wi & 1)) {
+    // fused strided data gradient (run_patch_gemm_x6c_fused): same tile / grid arithmetic as there
+    static const int fused_on = getenv("P2I_CONV_X6C_FUSED") ? atoi(getenv("P2I_CONV_X6C_FUSED")) : 1;
+    if (!fused_on) return false;
+    const int nimg = d->B * d->Ti, nH = d->Hi / 2, nW = d->Wi / 2;
+    int jb, jt, jh, jw;
+    pick_tile_dims(256, nimg, 1, nH, nW, jb, jt, jh, jw);
+    if (jt != 1 || jb * (jh + 1) * (jw + 1) > X6cTile<8>::MAXCSL) return false;
+    const long long tiles = (long long)ceil_div(nimg, jb) * ceil_div(nH, jh) * ceil_div(nW, jw) * ceil_div(d->Cin, 32);
+    static const int ksplit_on = getenv("P2I_X6C_KSPLIT") ? atoi(getenv("P2I_X6C_KSPLIT")) : 1;
+    const bool can_split = ksplit_on && (((d->kt * (d->Cout >> 4)) & 1) == 0);
+    return tiles >= x6c_min_wg() || (can_split && 2 * tiles >= x6c_min_wg());
+  }
   if (!on || d->kh != 3 || d->kw != 3 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1) return false;
   const bool flat = d->kt == 1 && d->st == 1 && d->pt == 0;           // 2-D layer (or frames convolved independently)
   const bool vol = d->kt == 3 && d->pt == 1 && d->st <= 2;            // 3 x 3 x 3, t stride 1 or 2: tap slices along t
@@ -477,14 +513,14 @@ __global__ __launch_bounds__(256) void x6c_post_act_kernel(float* __restrict__ y
   }
 }
 
-template <int NW, int TM>
+template <int NW, int TM, bool FUSED = false>
 static void x6c_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)patch_gemm_x6c_kernel<NW, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)patch_gemm_x6c_kernel<NW, TM, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((patch_gemm_x6c_kernel<NW, TM>), grid, dim3(64 * NW), lds, s, g);
+  hipLaunchKernelGGL((patch_gemm_x6c_kernel<NW, TM, FUSED>), grid, dim3(64 * NW), lds, s, g);
 }
 
 // returns 1 when the layer is not an x6c case (caller continues with the other engines)
@@ -574,6 +610,86 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
     const long long blocks = (n4 + 255) / 256;
     hipLaunchKernelGGL(x6c_post_act_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, g.dst, post_res, n4, post_act);
   }
+  return launch_status();
+}
+
+// ---- fused strided data gradient (stride (1,2,2), 3x3 or 3x3x3 taps, pad 1 in h and w; t stride 1): classes q = 2 pH + pW in the
+// order p2i_conv_dgrad builds them; class q must hold ns * {1, 2, 2, 4}[q] taps (slice-major), every class the same extents.
+// Returns 1 when the layer is not such a case.
+int run_patch_gemm_x6c_fused(PatchGeom g, const ClassSpec* css, int ncls, const uint16_t* wb, int ntaps_w, int* plan6, hipStream_t s, bool dry) {
+  static const int on = getenv("P2I_CONV_X6C_FUSED") ? atoi(getenv("P2I_CONV_X6C_FUSED")) : 1;
+  if (!on || ncls != 4 || (!dry && wb == nullptr) || g.src_y != nullptr || (g.Ck & 15) != 0 || g.Ck < 16) return 1;
+  static const int per[4] = {1, 2, 2, 4};
+  const int ns = css[0].ntaps;                            // class (0,0) has one tap per t slice
+  if (ns < 1 || ns > 3) return 1;
+  for (int q = 0; q < 4; ++q) {
+    const ClassSpec& c = css[q];
+    if (c.ntaps != ns * per[q] || c.mT != 1 || c.mH != 1 || c.mW != 1 || c.oH != 2 || c.oW != 2 || c.pH != (q >> 1) || c.pW != (q & 1)) return 1;
+    if (c.nT != css[0].nT || c.nH != css[0].nH || c.nW != css[0].nW || c.oT != css[0].oT || c.pT != css[0].pT) return 1;
+  }
+  if ((g.dH & 1) || (g.dW & 1) || css[0].nH * 2 != g.dH || css[0].nW * 2 != g.dW) return 1;
+  // slot -> (class, tap within the class's slice): slots 0-3 class 3, 4-5 class 2, 6-7 class 1, 8 class 0 (X6C_CLS)
+  static const int slot_cls[9] = {3, 3, 3, 3, 2, 2, 1, 1, 0}, slot_idx[9] = {0, 1, 2, 3, 0, 1, 0, 1, 0};
+  int sdt[3] = {0, 0, 0}, swt[3] = {0, 0, 0};
+  X6cGeom k{};
+  for (int j = 0; j < ns; ++j)
+    for (int sl = 0; sl < 9; ++sl) {
+      const ClassSpec& c = css[slot_cls[sl]];
+      const int i = j * per[slot_cls[sl]] + slot_idx[sl];      // class taps run slice-major (a outer)
+      const int i0 = slot_idx[sl];
+      if (c.dh[i] < 0 || c.dh[i] > 1 || c.dw[i] < 0 || c.dw[i] > 1) return 1;
+      if (c.dh[i] != c.dh[i0] || c.dw[i] != c.dw[i0]) return 1;
+      if (sl == 0) { sdt[j] = c.dt[i]; swt[j] = c.tw[i] - c.tw[i0]; }
+      else if (c.dt[i] != sdt[j] || c.tw[i] - c.tw[i0] != swt[j]) return 1;
+      if (j == 0) { k.tap_w[sl] = c.tw[i]; }
+    }
+  const ClassSpec& c0 = css[0];
+  const long long n_dst = (long long)g.B * g.Cm * g.dT * g.dH * g.dW;
+  const long long nimg = (long long)g.B * c0.nT;
+  if (nimg >= (1 << 24)) return 1;
+  // tile: 256 class-local positions of (b, t) images, 32 destination channels per workgroup (TM 1: four accumulator classes)
+  int jb, jt, jh, jw;
+  pick_tile_dims(256, (int)nimg, 1, c0.nH, c0.nW, jb, jt, jh, jw);
+  const int csl = jb * (jh + 1) * (jw + 1);
+  if (jt != 1 || csl > X6cTile<8>::MAXCSL) return 1;
+  const bool alias = g.dst == g.res || g.dst == g.mask_y;
+  const long long tiles = (long long)ceil_div((int)nimg, jb) * ceil_div(c0.nH, jh) * ceil_div(c0.nW, jw) * ceil_div(g.Cm, 32);
+  const int cps = g.Ck >> 4;
+  static const int ksplit_on = getenv("P2I_X6C_KSPLIT") ? atoi(getenv("P2I_X6C_KSPLIT")) : 1;
+  const bool can_split = ksplit_on && !alias && ((ns * cps) & 1) == 0 && c0.oT == 1 && c0.pT == 0 && c0.nT == g.dT;
+  const int min_wg = x6c_min_wg();
+  int ksplit = 1;
+  if (tiles < min_wg) {
+    if (can_split && 2 * tiles >= min_wg) ksplit = 2;
+    else return 1;
+  }
+  const unsigned long long sbytes = 4ull * g.B * g.Ck * g.sT * g.sH * g.sW;
+  if (sbytes >= 0x7FFFFFF0ull || 4ull * (unsigned long long)n_dst >= 0x7FFFFFF0ull) return 1;
+  if (dry) return 0;
+  k.src = g.src; k.dst = g.dst; k.wb = wb; k.bias = nullptr; k.res = g.res; k.mask_y = g.mask_y;
+  int tw_max = 0;
+  for (int q = 0; q < 4; ++q)
+    for (int i = 0; i < css[q].ntaps; ++i) tw_max = css[q].tw[i] > tw_max ? css[q].tw[i] : tw_max;
+  k.wb_bytes = (2u * (unsigned)ntaps_w + (unsigned)tw_max + 1u) * (unsigned)g.Ck * (unsigned)g.CmPad * 2u;
+  k.act_epi = P2I_ACT_NONE; k.mask_act = g.mask_act;
+  k.B = g.B; k.Ck = g.Ck; k.Cm = g.Cm; k.CmPad = g.CmPad;
+  k.sH = g.sH; k.sW = g.sW; k.dT = g.dT; k.dH = g.dH; k.dW = g.dW; k.nH = c0.nH; k.nW = c0.nW;
+  k.ljb = ilog2(jb); k.ljh = ilog2(jh); k.ljw = ilog2(jw);
+  k.eH = jh + 1; k.eW = jw + 1; k.CSl = csl; k.bH = 0; k.bW = 0;
+  k.nth = ceil_div(c0.nH, jh); k.ntw = ceil_div(c0.nW, jw);
+  k.mg_ew = magic_u16(k.eW); k.mg_eh = magic_u16(k.eH);
+  k.ntaps_w = ntaps_w; k.ksplit = ksplit; k.fused_atomic = ksplit > 1 ? 1 : 0;
+  k.sT = g.sT; k.nT = c0.nT; k.mT = 1; k.oT = c0.oT; k.pT = c0.pT; k.ns = ns;
+  k.sdt0 = sdt[0]; k.sdt1 = sdt[1]; k.sdt2 = sdt[2]; k.swt0 = swt[0]; k.swt1 = swt[1]; k.swt2 = swt[2];
+  for (int sl = 0; sl < 9; ++sl) {
+    const ClassSpec& c = css[slot_cls[sl]];
+    k.tap_off[sl] = c.dh[slot_idx[sl]] * k.eW + c.dw[slot_idx[sl]];
+  }
+  if (ksplit > 1 && hipMemsetAsync(g.dst, 0, sizeof(float) * (size_t)n_dst, s) != hipSuccess) return P2I_EINVAL;
+  const dim3 grid((unsigned)(ceil_div((int)nimg, jb) * k.nth * k.ntw), (unsigned)ceil_div(g.Cm, 32), (unsigned)ksplit);
+  const size_t lds = sizeof(float) * (size_t)((k.CSl + 3) & ~3) + 16 * (size_t)(6 * 18 * 32 + 2 * 6 * k.CSl);
+  if (plan6) { plan6[0] = 32; plan6[1] = 256; plan6[2] = ksplit; plan6[3] = 16; plan6[4] = 9; plan6[5] = 8; }
+  x6c_launch<8, 1, true>(k, grid, lds, s);
   return launch_status();
 }
 

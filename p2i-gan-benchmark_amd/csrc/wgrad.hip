@@ -671,8 +671,8 @@ static int launch_wgrad_reduce(const float* ws, int ns, long long slice, int Co,
 
 // wgrad_x6.hip: 3x3 stride-1 2-D layers with 64-multiple channel counts on the bf16 matrix pipe; 1 = not its case
 namespace p2i {
-int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* ws, long long ws_floats, int* ns_out,
-                 long long* slice_out, hipStream_t s);
+int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* dbias, float* ws, long long ws_floats,
+                 int* ns_out, long long* slice_out, hipStream_t s);
 }
 
 static thread_local float* g_wgrad_ws = nullptr;          // caller-owned slice scratch of the running p2i_conv_wgrad_ws call
@@ -695,13 +695,13 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
     g_wgrad_plan[0] = 2; g_wgrad_plan[1] = d->kt * d->kh * d->kw; g_wgrad_plan[2] = 0; g_wgrad_plan[3] = 1;
     return c1_wgrad(d, x, dy, dwp, dbias, s);
   }
-  if (y_act == nullptr && dbias == nullptr) {               // generator DO-Conv layers: bf16-split kernel where it applies
+  if (y_act == nullptr) {                                   // bf16-split kernel where it applies (spatial stride 1, 64-multiple channels)
     int ns6 = 0;
     long long slice6 = 0;
-    const int rc = run_wgrad_x6(d, x, dy, dwp, g_wgrad_ws, g_wgrad_ws_floats, &ns6, &slice6, s);
+    const int rc = run_wgrad_x6(d, x, dy, dwp, dbias, g_wgrad_ws, g_wgrad_ws_floats, &ns6, &slice6, s);
     if (rc != 1) {
       if (rc) return rc;
-      g_wgrad_plan[0] = 3; g_wgrad_plan[1] = 9; g_wgrad_plan[2] = 1; g_wgrad_plan[3] = 64;
+      g_wgrad_plan[0] = 3; g_wgrad_plan[1] = 9 * d->kt; g_wgrad_plan[2] = 1; g_wgrad_plan[3] = 64;
       if (ns6 >= 2) return launch_wgrad_reduce(g_wgrad_ws, ns6, slice6, d->Cout, (d->Cout + 31) / 32 * 32, dwp, s);
       return P2I_OK;
     }

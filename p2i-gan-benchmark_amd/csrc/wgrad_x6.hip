@@ -1,4 +1,5 @@
-// Weight gradient of the generator's 3x3 stride-1 DO-Conv layers (2-D, C_in and C_out multiples of 64) on the bf16 matrix pipe with
+// Weight gradient of 3x3 (and 3x3x3, as three t slices) layers with spatial stride 1 and C_in, C_out multiples of 64 -- the generator's
+// DO-Conv stack, the discriminators' 256 -> 256 and 128 -> 128 stride-(2,1,1) layers, with their bias gradient -- on the bf16 matrix pipe with
 // fp32 accuracy: both operands are activations (x and dy), each split exactly into three bf16 terms (hi + mid + lo, truncation
 // split), six v_mfma_f32_32x32x16_bf16 products per fp32 product accumulated in fp32, small terms first (conv_x6c.hip has the
 // numerics; the dropped products are <= 2^-23 |a b|).
@@ -30,14 +31,19 @@ typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
 struct Wx6Geom {
-  const float* x;        // (B, Cx, H, W)
-  const float* dy;       // (B, Co, H, W)
-  float* dwp;            // packed grad [9][Cx][CoPad]
+  const float* x;        // (B, Cx, sT, H, W)
+  const float* dy;       // (B, Co, nT, H, W)
+  float* dwp;            // packed grad [kt * 9][Cx][CoPad]
   float* partial;        // != null: slice s stores to partial + s * pstride (same indexing), wgrad_reduce_kernel sums
+  float* dbias;          // != null: db[o] += sum of dy (added atomically by the channel-block-0 / t-slice-0 workgroups)
   long long pstride;
   int B, Cx, Co, CoPad, H, W;
   int nth, ntw, ntiles;
   unsigned x_bytes, dy_bytes;
+  // time axis (3-D layers with spatial stride 1: the 27 taps are kt slices of 9, blockIdx.z = slice * nco + dy-channel block):
+  // "images" of the tile loop are (b, to) pairs; slice a pairs dy frame to with x frame to * mT + dt[a] (zero outside [0, sT))
+  int sT, nT, mT, nco;
+  int dt[3];
 };
 
 constexpr int WX_TH = 4, WX_TW = 16, WX_EW = WX_TW + 2, WX_EH = WX_TH + 2;
@@ -79,7 +85,9 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
   const int tg = wave >> 2, kh = (wave >> 1) & 1, mh = wave & 1;        // tap group, x-channel half, dy-channel half
   const int i16 = lane & 15, g16 = (lane >> 4) & 1, lhi = lane >> 5, l31 = lane & 31;
   const int HW = g.H * g.W;
-  const int cb = blockIdx.y, ob = blockIdx.z;
+  const int cb = blockIdx.y, ob = blockIdx.z % g.nco, ta = blockIdx.z / g.nco;      // x-channel block, dy-channel block, t slice
+  const int dta = ta == 2 ? g.dt[2] : (ta == 1 ? g.dt[1] : g.dt[0]);
+  const int xcs = g.sT * HW, ycs = g.nT * HW;                                     // channel strides (elements)
 
   // ---- staging items of this thread: (patch pixel q, 8-channel chunk); lanes run along q (coalesced loads, conflict-free writes)
   int x_rel[WX_NXI], x_dst[WX_NXI], x_qr[WX_NXI], x_qc[WX_NXI];
@@ -91,11 +99,11 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
     const int qr = q / WX_EW, qc = q - qr * WX_EW;
     x_qr[it] = in ? qr - 1 : -(1 << 20);                               // row / column relative to the tile origin; "never valid" when idle
     x_qc[it] = qc - 1;
-    x_rel[it] = ((cb * 64 + chunk * 8) * g.H + (qr - 1)) * g.W + (qc - 1);
+    x_rel[it] = (cb * 64 + chunk * 8) * xcs + (qr - 1) * g.W + (qc - 1);
     x_dst[it] = q * WX_ROW + chunk * 16;
   }
   const int y_chunk = tid >> 6, y_q = tid & 63;
-  const int y_rel = ((ob * 64 + y_chunk * 8) * g.H + (y_q >> 4)) * g.W + (y_q & 15);
+  const int y_rel = (ob * 64 + y_chunk * 8) * ycs + (y_q >> 4) * g.W + (y_q & 15);
   const int y_dst = WX_YOFF + y_q * WX_ROW + y_chunk * 16;
 
   // The three staging items of a thread (two x items, one dy item; 8 channel values each) live in sv[3][8].  Next tile's 24 loads are
@@ -113,27 +121,40 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
                                                        // the transposed reads interleaved with it need EXEC all ones)
   auto tile_ptrs = [&](int t) {
     const int tw = t % g.ntw, r0 = t / g.ntw;
-    const int th = r0 % g.nth, b = r0 / g.nth;
+    const int th = r0 % g.nth, img = r0 / g.nth;
+    const int b = img / g.nT, to = img - b * g.nT;
+    const int ti = to * g.mT + dta;                     // x frame of this t slice (outside the clip: the whole x tile reads as zero)
+    const bool tok = (unsigned)ti < (unsigned)g.sT;
     const int h0 = th * WX_TH, w0 = tw * WX_TW;
-    const int xorg = b * g.Cx * HW + h0 * g.W + w0, yorg = b * g.Co * HW + h0 * g.W + w0;
+    const int xorg = (b * g.Cx * g.sT + ti) * HW + h0 * g.W + w0, yorg = (b * g.Co * g.nT + to) * HW + h0 * g.W + w0;
 #pragma unroll
     for (int it = 0; it < WX_NXI; ++it) {
       const int h = h0 + x_qr[it], w = w0 + x_qc[it];
-      const bool ok = (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+      const bool ok = tok && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
       so[it] = ok ? 4u * (unsigned)(xorg + x_rel[it]) : 0xFFFFFF00u;
     }
     so[2] = 4u * (unsigned)(yorg + y_rel);
   };
-  const int chan_bytes = 4 * HW;
+  const int xchan_bytes = 4 * xcs, ychan_bytes = 4 * ycs;
   auto load_chunk = [&](int c) {                        // c = 0..7: loads 3c .. 3c+2 of the 24
 #pragma unroll
     for (int f = 3 * c; f < 3 * c + 3; ++f)
-      sv[f >> 3][f & 7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((f >> 3) == 2 ? rs_y : rs_x, so[f >> 3], (f & 7) * chan_bytes, 0));
+      sv[f >> 3][f & 7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((f >> 3) == 2 ? rs_y : rs_x, so[f >> 3],
+                                                                                      (f & 7) * ((f >> 3) == 2 ? ychan_bytes : xchan_bytes), 0));
   };
+  // bias gradient: every dy value passes through sv[2] exactly once per (x-channel block, t slice) pass; the blocks with cb == 0
+  // and t slice 0 sum theirs (wave = 8 channels, lane = pixel of the tile)
+  const bool do_bias = g.dbias != nullptr && cb == 0 && ta == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float bias_w = 1.f;                                   // 0 while the loop re-stages its last tile (nothing new)
   // c = 0..8: plane c % 3 (hi, mid, lo) of item c / 3 -> packed bf16x8 to LDS; the item's values become their own remainder
   auto split_chunk = [&](int c, unsigned char* buf) {
     const int it = c / 3, pl = c % 3;
     float (&v)[8] = sv[it];
+    if (c == 6 && do_bias) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum[j] += bias_w * v[j];
+    }
     u32x4w w;
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = wx_pack(v[2 * j], v[2 * j + 1]);
@@ -192,6 +213,7 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
     const int tn = t + gridDim.x;
     const bool more = tn < g.ntiles;
     tile_ptrs(more ? tn : t);                          // (the last tile re-stages itself into the idle buffer: branch-free loop body)
+    bias_w = more ? 1.f : 0.f;
     const unsigned char* buf = wsm + cur * WX_BUF;
     unsigned char* nbuf = wsm + (cur ^ 1) * WX_BUF;    // read last in the previous tile (all waves are past its barrier)
     // software pipeline over the 18 tap-steps: step i+1's six operand reads (and the next K-step's six dy reads) are issued under
@@ -262,8 +284,16 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
       for (int e = 0; e < 4; ++e) acc[4][4 * j4 + e] += v[e];
     }
   }
-  float* dst = (g.partial ? g.partial + (size_t)blockIdx.x * g.pstride : g.dwp) + ((size_t)cb * 64 + 32 * kh + 4 * lhi) * g.CoPad + ob * 64 + 32 * mh + l31;
   const size_t tap_stride = (size_t)g.Cx * g.CoPad;
+  float* dst = (g.partial ? g.partial + (size_t)blockIdx.x * g.pstride : g.dwp) + (size_t)ta * 9 * tap_stride +
+               ((size_t)cb * 64 + 32 * kh + 4 * lhi) * g.CoPad + ob * 64 + 32 * mh + l31;
+  if (do_bias) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float sj = wave_sum(bsum[j]);
+      if (lane == 0) atomicAdd(g.dbias + ob * 64 + y_chunk * 8 + j, sj);
+    }
+  }
   auto emit = [&](auto&& put) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -278,23 +308,29 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
 }
 
 // 0 = launched (plan filled), 1 = not a case of this kernel (caller continues with the f32 kernels)
-int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* ws, long long ws_floats, int* ns_out,
-                 long long* slice_out, hipStream_t s) {
+int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* dbias, float* ws, long long ws_floats,
+                 int* ns_out, long long* slice_out, hipStream_t s) {
   { const char* e = getenv("P2I_WGRAD_X6"); if (e && atoi(e) == 0) return 1; }     // read per call: tests run both engines in one process
-  if (d->kt != 1 || d->kh != 3 || d->kw != 3 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1 || d->pt != 0) return 1;
-  if (d->Ti != 1 || d->To != 1 || (d->Cin & 63) || (d->Cout & 63) || (d->Wo % WX_TW) || (d->Ho % WX_TH)) return 1;
-  const long long nx = (long long)d->B * d->Cin * d->Hi * d->Wi, ny = (long long)d->B * d->Cout * d->Ho * d->Wo;
+  if (d->kh != 3 || d->kw != 3 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1) return 1;
+  const bool flat = d->kt == 1 && d->st == 1 && d->pt == 0;             // 2-D layer (or frames convolved independently)
+  const bool vol = d->kt == 3 && d->pt == 1 && d->st <= 2;              // 3 x 3 x 3: three t slices of nine taps
+  if (!flat && !vol) return 1;
+  if ((d->Cin & 63) || (d->Cout & 63) || (d->Wo % WX_TW) || (d->Ho % WX_TH)) return 1;
+  const long long nx = (long long)d->B * d->Cin * d->Ti * d->Hi * d->Wi, ny = (long long)d->B * d->Cout * d->To * d->Ho * d->Wo;
   if (nx >= (1ll << 30) - 64 || ny >= (1ll << 30) - 64) return 1;        // byte offsets in 32 bits, below the out-of-range marker
   Wx6Geom g{};
-  g.x = x; g.dy = dy; g.dwp = dwp;
+  g.x = x; g.dy = dy; g.dwp = dwp; g.dbias = dbias;
   g.B = d->B; g.Cx = d->Cin; g.Co = d->Cout; g.CoPad = (d->Cout + 31) / 32 * 32; g.H = d->Ho; g.W = d->Wo;
   g.x_bytes = (unsigned)(4 * nx); g.dy_bytes = (unsigned)(4 * ny);
-  g.nth = d->Ho / WX_TH; g.ntw = d->Wo / WX_TW; g.ntiles = d->B * g.nth * g.ntw;
+  g.sT = d->Ti; g.nT = d->To; g.mT = d->st;
+  for (int a = 0; a < d->kt; ++a) g.dt[a] = a - d->pt;
+  g.nth = d->Ho / WX_TH; g.ntw = d->Wo / WX_TW; g.ntiles = d->B * d->To * g.nth * g.ntw;
   const int ncb = d->Cin / 64, nco = d->Cout / 64;
-  int ns = 256 / (ncb * nco);                          // LDS admits one workgroup per CU
+  g.nco = nco;
+  int ns = 256 / (ncb * nco * d->kt);                  // LDS admits one workgroup per CU
   if (ns < 1) ns = 1;
   if (ns > g.ntiles) ns = g.ntiles;
-  const long long slice = 9ll * d->Cin * g.CoPad;
+  const long long slice = 9ll * d->kt * d->Cin * g.CoPad;
   const bool sliced = ns >= 2 && ws != nullptr && slice * ns <= ws_floats && slice < (1ll << 31);
   if (ns >= 2 && !sliced) return 1;                    // no scratch for the slices: the f32 kernel's atomic path
   g.partial = sliced ? ws : nullptr;
@@ -304,7 +340,7 @@ int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float*
     (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_x6_kernel, dim3(ns, ncb, nco), dim3(512), 2 * WX_BUF + 1024, s, g);
+  hipLaunchKernelGGL(wgrad_x6_kernel, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
   *ns_out = sliced ? ns : 0;
   *slice_out = slice;
   return launch_status();

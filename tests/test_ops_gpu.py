@@ -50,6 +50,10 @@ CONV_CASES = [
     ("d3d_tstride16", 3, 2, 32, 48, (6, 16, 16), (3, 3, 3), (2, 1, 1), (1, 1, 1), "leaky", True, False),   # x6c with tap slices along t (stride 2 in t)
     ("d3d_t1_16", 3, 1, 16, 32, (5, 16, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1), "none", True, True),            # x6c with tap slices, stride 1, odd T
     ("d3d_1x1x1", 3, 2, 128, 1, (4, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0), "none", True, False),
+    ("d2d_64_bias", 2, 2, 64, 128, (16, 32), (3, 3), (1, 1), (1, 1), "leaky", True, False),                  # wgrad_x6 with the bias gradient
+    ("d3d_tstride64", 3, 2, 64, 128, (6, 16, 16), (3, 3, 3), (2, 1, 1), (1, 1, 1), "leaky", True, False),     # wgrad_x6 / x6c with t slices, t stride 2
+    ("d3d_t1_64", 3, 1, 64, 64, (5, 8, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1), "none", True, True),             # t stride 1, odd T
+    ("d2d_256_to1_wide", 2, 2, 40, 1, (9, 70), (3, 3), (1, 1), (1, 1), "none", True, False),                  # o1_fwd_kernel: three column tiles, odd rows
 ]
 
 
@@ -194,11 +198,13 @@ def test_conv_fwd_dgrad_wgrad(ops, engine, case):
     wp_f, wp_d = ops.weight_pack(w.detach().to(dev))
     xg = x.detach().to(dev)
     yg = ops.conv_fwd(spec, xg, wp_f, bias.detach().to(dev) if has_bias else None, res.to(dev) if has_res else None, act_code)
-    x6c_layer = engine.startswith("x6c") and nd == 2 and k == (3, 3) and st == (1, 1) and name not in ("g3x3_tiny4", "g3x3_w128", "d2d_to1", "g3x3_1024_atomic")
+    x6c_layer = engine.startswith("x6c") and nd == 2 and k == (3, 3) and st == (1, 1) and name not in ("g3x3_tiny4", "g3x3_w128", "d2d_to1", "g3x3_1024_atomic", "d2d_256_to1_wide")
     # (those three: a 256-position tile spans 16 or 4 images / is 2 x 128 + halo -- patches above the 384-pixel limit, f32 engine)
-    x6c_layer = x6c_layer or (engine.startswith("x6c") and name in ("d3d_tstride16", "d3d_t1_16"))
+    x6c_layer = x6c_layer or (engine.startswith("x6c") and name in ("d3d_tstride16", "d3d_t1_16", "d3d_tstride64", "d3d_t1_64"))
     if x6c_layer and Cin % 16 == 0:
         assert _last_plan(ops)[5] == 7, (name, _last_plan(ops))
+    if name in ("d2d_to1", "d2d_256_to1_wide"):
+        assert _last_plan(ops)[5] == 3, (name, _last_plan(ops))      # single-output-channel bandwidth kernel (o1_fwd_kernel)
     assert rel_err(yg.cpu().numpy(), out.detach().numpy()) < TOL_OP
 
     # backward: dy_eff = gout * act'(y).  The HIP path gets the post-activation tensor (before residual).
@@ -211,10 +217,13 @@ def test_conv_fwd_dgrad_wgrad(ops, engine, case):
     dx2 = ops.conv_dgrad(spec, gin.detach().to(dev).contiguous(), wp_d, tuple(x.shape), add=addt.to(dev), mask_y=mk.to(dev), mask_act=ops.ACT_RELU)
     if x6c_layer and Cout % 16 == 0 and Cin > 1:
         assert _last_plan(ops)[5] == 7, (name, _last_plan(ops))
+    if engine.startswith("x6c") and name in ("d2d_s2", "d2d_s2_odd", "d3d_mid"):
+        assert _last_plan(ops)[5] == 8, (name, _last_plan(ops))      # stride-(.,2,2) data gradient: four parity classes fused on the split pipe
     assert rel_err(dx2.cpu().numpy(), ((x.grad + addt) * (mk > 0)).numpy()) < TOL_OP
     # prologue-free weight gradient on the pre-masked gradient (what the model code uses)
     dwp2, db2 = ops.conv_wgrad(spec, xg, gin.detach().to(dev).contiguous(), want_bias=has_bias)
-    if nd == 2 and k == (3, 3) and st == (1, 1) and Cin % 64 == 0 and Cout % 64 == 0 and sp[0] % 4 == 0 and sp[1] % 16 == 0 and not has_bias:
+    vol3 = nd == 3 and k == (3, 3, 3) and pd == (1, 1, 1) and st[0] <= 2
+    if (nd == 2 or vol3) and k[-2:] == (3, 3) and st[-2:] == (1, 1) and Cin % 64 == 0 and Cout % 64 == 0 and sp[-2] % 4 == 0 and sp[-1] % 16 == 0:
         import ctypes
         wplan = (ctypes.c_int * 4)()
         ops._hip.load().p2i_wgrad_last_plan(wplan)
@@ -599,3 +608,41 @@ def test_bf16_split_kernels_hold_fp32_accuracy_vs_float64(ops, monkeypatch, C, S
     for i, kind in enumerate(("fwd", "dgrad", "wgrad")):
         assert err["auto"][i] < 5e-6, (kind, err)
         assert err["auto"][i] <= 2.0 * err["f32"][i] + 2e-7, (kind, err)
+
+
+def test_x6c_fused_strided_dgrad_matches_f32_engine(ops, monkeypatch):
+    """Data gradient of stride-(.,2,2) 3x3 / 3x3x3 layers on the bf16-split pipe (patch_gemm_x6c_kernel<8,1,true>: the four input-parity
+    classes of the destination in one workgroup, float2 pair stores) against the f32 fused kernel, with the epilogue's add + leaky
+    mask; also the split-K form (class pairs ADDED into the zeroed destination) and run-to-run reproducibility."""
+    old = ops.CONV_ENGINE
+    try:
+        for (cin, cout, sp, k3, s3, p3) in [(64, 128, (32, 32), (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+                                            (32, 64, (4, 24, 40), (3, 3, 3), (1, 2, 2), (1, 1, 1))]:
+            spec = ops.ConvSpec(cin, cout, k3, s3, p3)
+            B = 2
+            xs = (B, cin, *sp)
+            to, ho, wo = spec.out_dims(*((1,) + sp if len(sp) == 2 else sp))
+            ys = (B, cout, ho, wo) if len(sp) == 2 else (B, cout, to, ho, wo)
+            _, wp_d = ops.weight_pack(_rand(cout, cin, spec.ntaps, seed=31, scale=0.05).cuda())
+            dy, add, mk = _rand(*ys, seed=32).cuda(), _rand(*xs, seed=33).cuda(), _rand(*xs, seed=34).cuda()
+            ops.CONV_ENGINE = "f32"
+            ref = ops.conv_dgrad(spec, dy, wp_d, xs, add=add, mask_y=mk, mask_act=ops.ACT_LEAKY)
+            assert _last_plan(ops)[5] > 10                               # the f32 fused kernel
+            ops.CONV_ENGINE = "auto"
+            monkeypatch.setenv("P2I_X6C_MIN_WG", "1")
+            got = ops.conv_dgrad(spec, dy, wp_d, xs, add=add, mask_y=mk, mask_act=ops.ACT_LEAKY)
+            assert _last_plan(ops)[5] == 8 and _last_plan(ops)[2] == 1, _last_plan(ops)
+            assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 5e-6
+            ntiles = None
+            for mw in (3, 5, 9, 17, 33):                                 # first threshold that only the split-K launch reaches
+                monkeypatch.setenv("P2I_X6C_MIN_WG", str(mw))
+                g2 = ops.conv_dgrad(spec, dy, wp_d, xs, add=add, mask_y=mk, mask_act=ops.ACT_LEAKY)
+                if _last_plan(ops)[5] == 8 and _last_plan(ops)[2] == 2:
+                    ntiles = mw
+                    break
+            assert ntiles is not None, "no split-K launch seen"
+            assert rel_err(g2.cpu().numpy(), ref.cpu().numpy()) < 5e-6
+            g3 = ops.conv_dgrad(spec, dy, wp_d, xs, add=add, mask_y=mk, mask_act=ops.ACT_LEAKY)
+            assert torch.equal(g2, g3)                                   # two addends per element: order-independent
+    finally:
+        ops.CONV_ENGINE = old
