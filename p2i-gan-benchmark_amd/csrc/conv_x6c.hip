@@ -434,6 +434,8 @@ static int x6c_min_wg() { const char* e = getenv("P2I_X6C_MIN_WG"); return e ? a
 // P2I_X6C_TILE=<NW><TM> (82, 81) forces one variant (tests, tuning)
 static int x6c_forced() { const char* e = getenv("P2I_X6C_TILE"); return e ? atoi(e) : 0; }
 
+static int x6c_fused_ksplit() { const char* e = getenv("P2I_X6C_FUSED_KSPLIT"); return e ? atoi(e) : 0; }   // read per call (tests)
+
 struct X6cVariant { int NW, TM; };
 static const X6cVariant kX6cVariants[] = {{8, 2}, {8, 1}};      // in order of per-CU efficiency
 
@@ -477,8 +479,7 @@ bool x6c_would_take(const p2i_conv_desc* d, bool dgrad, int act_epi) {
     pick_tile_dims(256, nimg, 1, nH, nW, jb, jt, jh, jw);
     if (jt != 1 || jb * (jh + 1) * (jw + 1) > X6cTile<8>::MAXCSL) return false;
     const long long tiles = (long long)ceil_div(nimg, jb) * ceil_div(nH, jh) * ceil_div(nW, jw) * ceil_div(d->Cin, 32);
-    static const int ksplit_on = getenv("P2I_X6C_KSPLIT") ? atoi(getenv("P2I_X6C_KSPLIT")) : 1;
-    const bool can_split = ksplit_on && (((d->kt * (d->Cout >> 4)) & 1) == 0);
+    const bool can_split = x6c_fused_ksplit() && (((d->kt * (d->Cout >> 4)) & 1) == 0);
     return tiles >= x6c_min_wg() || (can_split && 2 * tiles >= x6c_min_wg());
   }
   if (!on || d->kh != 3 || d->kw != 3 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1) return false;
@@ -655,8 +656,9 @@ int run_patch_gemm_x6c_fused(PatchGeom g, const ClassSpec* css, int ncls, const 
   const bool alias = g.dst == g.res || g.dst == g.mask_y;
   const long long tiles = (long long)ceil_div((int)nimg, jb) * ceil_div(c0.nH, jh) * ceil_div(c0.nW, jw) * ceil_div(g.Cm, 32);
   const int cps = g.Ck >> 4;
-  static const int ksplit_on = getenv("P2I_X6C_KSPLIT") ? atoi(getenv("P2I_X6C_KSPLIT")) : 1;
-  const bool can_split = ksplit_on && !alias && ((ns * cps) & 1) == 0 && c0.oT == 1 && c0.pT == 0 && c0.nT == g.dT;
+  // split-K for layers with too few tiles: measured SLOWER than the f32 fused kernel on the one layer of the step it would take
+  // (128 -> 256 stride 2 at B = 8: 90.6 vs 72 us, the float2 pairs become two atomics each), so it is off unless asked for
+  const bool can_split = x6c_fused_ksplit() && !alias && ((ns * cps) & 1) == 0 && c0.oT == 1 && c0.pT == 0 && c0.nT == g.dT;
   const int min_wg = x6c_min_wg();
   int ksplit = 1;
   if (tiles < min_wg) {

@@ -157,7 +157,7 @@ class Trainer:
             if hasattr(self.train_loader.sampler, "set_epoch"):
                 self.train_loader.sampler.set_epoch(epoch)
             run, steps = None, 0
-            # batches arrive on the device one step ahead (helper thread + copy stream: data/prefetch.py); train.prefetch=false
+            # batches arrive on the device one step ahead (pinned staging + copy stream: data/prefetch.py); train.prefetch=false
             # keeps the reference's in-line hand-over (train.py:468-473)
             feed = DevicePrefetcher(self.train_loader, self.device) if self.cfg.get("train", {}).get("prefetch", True) else \
                 (self._batch(b) for b in self.train_loader)

@@ -634,6 +634,7 @@ def test_x6c_fused_strided_dgrad_matches_f32_engine(ops, monkeypatch):
             assert _last_plan(ops)[5] == 8 and _last_plan(ops)[2] == 1, _last_plan(ops)
             assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 5e-6
             ntiles = None
+            monkeypatch.setenv("P2I_X6C_FUSED_KSPLIT", "1")              # (off by default: slower than the f32 fused kernel where it would apply)
             for mw in (3, 5, 9, 17, 33):                                 # first threshold that only the split-K launch reaches
                 monkeypatch.setenv("P2I_X6C_MIN_WG", str(mw))
                 g2 = ops.conv_dgrad(spec, dy, wp_d, xs, add=add, mask_y=mk, mask_act=ops.ACT_LEAKY)
@@ -644,5 +645,6 @@ def test_x6c_fused_strided_dgrad_matches_f32_engine(ops, monkeypatch):
             assert rel_err(g2.cpu().numpy(), ref.cpu().numpy()) < 5e-6
             g3 = ops.conv_dgrad(spec, dy, wp_d, xs, add=add, mask_y=mk, mask_act=ops.ACT_LEAKY)
             assert torch.equal(g2, g3)                                   # two addends per element: order-independent
+            monkeypatch.delenv("P2I_X6C_FUSED_KSPLIT")
     finally:
         ops.CONV_ENGINE = old
