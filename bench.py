@@ -246,7 +246,7 @@ def loader_leg(eng, dev, B, steps, warmup, workers):
         return {"step_ms_with_loader": round(ms, 3), "frames_per_s_with_loader": round(B * T / ms * 1e3, 1),
                 "loader_samples_per_s": round(host_sps, 1), "loader_needs_samples_per_s": None,
                 "loader": {"store": "synthetic train.zarr, %d windows of %d frames from 64 events (zarr_lite, uncompressed uint8 chunks (20,128,128))" % (nwin, T),
-                           "num_workers": workers, "device_assemble": True, "prefetch": "DevicePrefetcher (in line, one batch ahead: pinned staging, copy stream)",
+                           "num_workers": workers, "device_assemble": True, "prefetch": "DevicePrefetcher (in line, one batch ahead on a copy stream)",
                            "mask": "sti block 10", "steps": steps}}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

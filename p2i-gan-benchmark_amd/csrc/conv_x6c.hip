@@ -125,18 +125,25 @@ __device__ __forceinline__ void x6c_wait_vm(int n) {
 #undef P2I_WC
 }
 
-template <int NW, int TM, bool FUSED = false>
+// TPS = taps per pipeline stage (one hand-over barrier per stage): 3 = one kernel row, 9 = the whole 16-channel chunk.  A 32-channel
+// tile (TM 1) has only 18 MFMAs per wave and kernel-row stage, against which the barrier, the counted waits and the DMA issue of a
+// stage weigh twice as much as in the 64-channel tile (stamped: 42 % vs 63 % of the MFMA-bound time in the loop); with whole-chunk
+// stages those costs are paid once per 54 MFMAs and the two waves of a SIMD drift apart inside the stage (one's staging work under
+// the other's MFMAs).  The weight ring is then 3 slots of 27 KB (TM 1), filled two chunks ahead.
+template <int NW, int TM, bool FUSED = false, int TPS = 3>
 __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g) {
   constexpr int NCLS = FUSED ? 4 : 1;
+  constexpr int NSTG = 9 / TPS;                           // stages per chunk
+  static_assert(TPS == 3 || TPS == 9, "taps per stage");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef P2I_STAMP
   unsigned long long st_entry, st_prev, st_wait = 0, st_bar = 0, st_issue = 0, st_mfma = 0, st_loop0;
   X6C_NOW(st_entry);
 #endif
   constexpr int MB = 32 * TM, NTHR = 64 * NW, NI = X6cTile<NW>::NI;
-  constexpr int RING = TM == 2 ? 4 : 6, LEAD = RING - 1;  // a stage is ~1.2 us (TM 2) / ~0.6 us (TM 1) of MFMAs, an L2 -> LDS DMA ~2 us under load
-  constexpr int WST = 18 * MB;                            // 16-B elements of one stage's weights: [3 planes][3 taps][2 k-groups][MB m]
-  constexpr int NWI = 18 * MB / 64;                       // ... = this many 64-lane DMA instructions (TM 1: one covers both k-groups of 32 m)
+  constexpr int RING = TPS == 9 ? 3 : (TM == 2 ? 4 : 6), LEAD = RING - 1;  // a kernel-row stage is ~1.2 us (TM 2) / ~0.6 us (TM 1) of MFMAs, an L2 -> LDS DMA ~2 us under load
+  constexpr int WST = 6 * TPS * MB;                       // 16-B elements of one stage's weights: [3 planes][TPS taps][2 k-groups][MB m]
+  constexpr int NWI = WST / 64;                           // ... = this many 64-lane DMA instructions (TM 1: one covers both k-groups of 32 m)
   const int CSl = g.CSl;
   int* ptab = reinterpret_cast<int*>(smem);                               // [CSl] element offset of patch pixel e, channel 0 (-1: outside)
   const int ptab_sz = (CSl + 3) & ~3;
@@ -228,9 +235,13 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
       const unsigned long long sq_u = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)sq) & 0xffffffffull;
       const unsigned long long sq_hi = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)sq >> 32));
       const unsigned long long sbase = sq_u | (sq_hi << 32);
+      // sbase is fresh from v_readfirstlane: a VMEM instruction that reads an SGPR written by the VALU needs 5 wait states, and hipcc
+      // pads nothing for an asm statement (a build whose schedule put the two back to back faulted on a garbage base)
 #pragma unroll
-      for (int it = 0; it < NI; ++it)
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(pv[it][q]) : "v"(voff[it]), "s"(sbase) : "memory");
+      for (int it = 0; it < NI; ++it) {
+        if (it == 0) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(pv[it][q]) : "v"(voff[it]), "s"(sbase) : "memory");
+        else asm volatile("global_load_dword %0, %1, %2" : "=v"(pv[it][q]) : "v"(voff[it]), "s"(sbase) : "memory");
+      }
     }
   };
   auto split_patch = [&](u32x4c* pb) {
@@ -251,17 +262,17 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
   // The byte offset of instruction r's source at chunk 0 is computed ONCE per kernel row (w_soff[r][b]): inside the loop the
   // look-up of g.tap_w[] is a scalar load + s_waitcnt lgkmcnt(0) per instruction, 1300-1500 cycles per stage (stamped).
   constexpr int NWR = (NWI + NW - 1) / NW;
-  int w_soff[NWR][3];
+  int w_soff[NWR][NSTG];
   unsigned w_dst[NWR];
 #pragma unroll
   for (int r = 0; r < NWR; ++r) {
     const int u = wave + NW * r;
     // TM 2: u = (plane, tap, k-group); TM 1: u = (plane, tap), the two k-groups ride in the lane halves
     const int pt = TM == 2 ? u >> 1 : u, kg = TM == 2 ? u & 1 : 0;
-    const int p = pt / 3, tl = pt % 3;
+    const int p = pt / TPS, tl = pt % TPS;
 #pragma unroll
-    for (int b = 0; b < 3; ++b)
-      w_soff[r][b] = u < NWI ? __builtin_amdgcn_readfirstlane((((p * g.ntaps_w + g.tap_w[3 * b + tl]) * KCt + kg) * g.CmPad + o0) * 16) : 0;
+    for (int b = 0; b < NSTG; ++b)
+      w_soff[r][b] = u < NWI ? __builtin_amdgcn_readfirstlane((((p * g.ntaps_w + g.tap_w[TPS * b + tl]) * KCt + kg) * g.CmPad + o0) * 16) : 0;
     w_dst[r] = wbuf_la + 16u * (unsigned)(u * 64);
   }
   const int w_cstep = 2 * g.CmPad * 16;                                // one 16-channel chunk further
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
   };
 
   const int nch = (g.ns * cps) / g.ksplit;            // this workgroup's chunks: [c0, c0 + nch)
-  const int nst = 3 * nch;
+  const int nst = NSTG * nch;
   const int nw_mine = (NWI / NW) + (wave < NWI % NW ? 1 : 0);          // this wave's DMA instructions per weight batch
   constexpr int NPL = 8 * NI;                                           // patch loads per thread and chunk
   auto nwb = [&](int st) { return st < nst ? nw_mine : 0; };
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
   load_patch(0);
 #pragma unroll
   for (int st = 0; st < LEAD; ++st)
-    if (st < nst) issue_w(st / 3, st % 3, st % RING);
+    if (st < nst) issue_w(st / NSTG, st % NSTG, st % RING);
   {
     int n = 0;
 #pragma unroll
@@ -306,12 +317,12 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
   // front of the LAST tap of stage s, and that tap's MFMAs cover the first reads of stage s+1.  Three operand register sets.
   u32x4c A[3][TM][3], Bv[3][3];
   auto load_tap = [&](const u32x4c* wsl, const u32x4c* pbp, int tap, int buf) {
-    const int tl = tap % 3;
+    const int tl = tap % TPS;
     const int to = toff[tap];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) A[buf][i][p] = wsl[((p * 3 + tl) * 2) * MB + 32 * i];
+      for (int i = 0; i < TM; ++i) A[buf][i][p] = wsl[((p * TPS + tl) * 2) * MB + 32 * i];
       Bv[buf][p] = pbp[p * 2 * CSl + to];
     }
   };
@@ -343,38 +354,52 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
     const u32x4c* pbn = planes + ((c + 1) & 1) * PST + lane_base;
     const bool more_c = c + 1 < nch;
 #pragma unroll
-    for (int b = 0; b < 3; ++b, ++s) {
+    for (int b = 0; b < NSTG; ++b, ++s) {
       const int sa = s + LEAD;
       if (b == 0 && more_c) load_patch(c + 1);
-      if (b == 2 && more_c) {
-        // patch loads were issued in stage s-2; younger: the weights issued in stages s-2 and s-1
-        x6c_wait_vm(nwb(s - 2 + LEAD) + nwb(s - 1 + LEAD));
-        __builtin_amdgcn_sched_barrier(0);
-        split_patch(planes + ((c + 1) & 1) * PST);     // buffer read last in chunk c-1
+      if constexpr (TPS == 3) {
+        if (b == 2 && more_c) {
+          // patch loads were issued in stage s-2; younger: the weights issued in stages s-2 and s-1
+          x6c_wait_vm(nwb(s - 2 + LEAD) + nwb(s - 1 + LEAD));
+          __builtin_amdgcn_sched_barrier(0);
+          split_patch(planes + ((c + 1) & 1) * PST);     // buffer read last in chunk c-1
+        }
       }
-      if (sa < nst) issue_w(c + (b + LEAD) / 3, (b + LEAD) % 3, sa % RING);   // slot read last in stage s-1 (complete before its barrier)
+      if (sa < nst) issue_w(c + (b + LEAD) / NSTG, (b + LEAD) % NSTG, sa % RING);   // slot read last in stage s-1 (complete before its barrier)
       X6C_ACC(st_issue, st_prev);                                  // patch loads / split pass / weight DMA issue
       const u32x4c* wsl = wlane + (s % RING) * WST;
       __builtin_amdgcn_sched_barrier(0);
-      load_tap(wsl, pb, 3 * b + 1, 1);
-      mfma_tap(0, 3 * b);
-      ilv();
-      __builtin_amdgcn_sched_barrier(0);
-      load_tap(wsl, pb, 3 * b + 2, 2);
-      mfma_tap(1, 3 * b + 1);
-      ilv();
-      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < TPS - 1; ++t) {
+        if constexpr (TPS == 9) {
+          if (t == 6 && more_c) {
+            // whole-chunk stage: the patch loads went out at the top of THIS stage, six taps of MFMAs ago; younger: only this
+            // stage's weight batch.  (The wait also retires the weights of stage s+1, issued a stage earlier.)
+            x6c_wait_vm(nwb(sa));
+            __builtin_amdgcn_sched_barrier(0);
+            split_patch(planes + ((c + 1) & 1) * PST);   // buffer read last in chunk c-1
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        load_tap(wsl, pb, TPS * b + t + 1, (t + 1) % 3);
+        mfma_tap(t % 3, TPS * b + t);
+        ilv();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       X6C_ACC(st_mfma, st_prev);
       // stage s+1 needs its weights W(s+1); everything issued after that batch may stay in flight: W(s+2) .. W(s+LEAD), and the
-      // patch loads of the stages s+2-LEAD .. s that start a chunk
+      // patch loads of the stages s+2-LEAD .. s that start a chunk (kernel-row stages only: a whole-chunk stage has split its
+      // patch already)
       {
         int n = 0;
 #pragma unroll
         for (int j = 2; j <= LEAD; ++j) n += nwb(s + j);
+        if constexpr (TPS == 3) {
 #pragma unroll
-        for (int j = 0; j <= LEAD - 2; ++j) {
-          const int bj = ((b - j) % 3 + 3) % 3;                     // kernel row of stage s-j
-          if (bj == 0 && s - j >= 0 && (s - j) / 3 + 1 < nch) n += NPL;
+          for (int j = 0; j <= LEAD - 2; ++j) {
+            const int bj = ((b - j) % 3 + 3) % 3;                     // kernel row of stage s-j
+            if (bj == 0 && s - j >= 0 && (s - j) / 3 + 1 < nch) n += NPL;
+          }
         }
         x6c_wait_vm(n);
       }
@@ -382,8 +407,8 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
       X6C_ACC(st_wait, st_prev);
       __builtin_amdgcn_s_barrier();
       X6C_ACC(st_bar, st_prev);
-      if (s + 1 < nst) load_tap(wlane + ((s + 1) % RING) * WST, b == 2 ? pbn : pb, b == 2 ? 0 : 3 * b + 3, 0);
-      mfma_tap(2, 3 * b + 2);
+      if (s + 1 < nst) load_tap(wlane + ((s + 1) % RING) * WST, b == NSTG - 1 ? pbn : pb, b == NSTG - 1 ? 0 : TPS * b + TPS, 0);
+      mfma_tap(2, TPS * b + TPS - 1);
       ilv();
       __builtin_amdgcn_sched_barrier(0);
       X6C_ACC(st_mfma, st_prev);
@@ -514,14 +539,20 @@ __global__ __launch_bounds__(256) void x6c_post_act_kernel(float* __restrict__ y
   }
 }
 
-template <int NW, int TM, bool FUSED = false>
+template <int NW, int TM, bool FUSED = false, int TPS = 3>
 static void x6c_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)patch_gemm_x6c_kernel<NW, TM, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)patch_gemm_x6c_kernel<NW, TM, FUSED, TPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((patch_gemm_x6c_kernel<NW, TM, FUSED>), grid, dim3(64 * NW), lds, s, g);
+  hipLaunchKernelGGL((patch_gemm_x6c_kernel<NW, TM, FUSED, TPS>), grid, dim3(64 * NW), lds, s, g);
+}
+// taps per stage of the 32-channel tiles: 9 (whole chunk) unless P2I_X6C_TPS=3 (read per call: A/B runs)
+static int x6c_tps1() { const char* e = getenv("P2I_X6C_TPS"); return (e && atoi(e) == 3) ? 3 : 9; }
+static size_t x6c_lds_bytes(int csl, int tm, int tps) {
+  const int ring = tps == 9 ? 3 : (tm == 2 ? 4 : 6);
+  return sizeof(float) * (size_t)((csl + 3) & ~3) + 16 * (size_t)(ring * 6 * tps * 32 * tm + 2 * 6 * csl);
 }
 
 // returns 1 when the layer is not an x6c case (caller continues with the other engines)
@@ -583,8 +614,8 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   for (int i = 0; i < cs.ntaps; ++i) tw_max = cs.tw[i] > tw_max ? cs.tw[i] : tw_max;
   g.wb_bytes = (2u * (unsigned)ntaps_w + (unsigned)tw_max + 1u) * (unsigned)g.Ck * (unsigned)g.CmPad * 2u;
   g.nclass = 1;
-  const int ring = tv.TM == 2 ? 4 : 6;
-  const size_t lds = sizeof(float) * (size_t)((g.CSl + 3) & ~3) + 16 * (size_t)(ring * 18 * 32 * tv.TM + 2 * 6 * g.CSl);
+  const int tps = tv.TM == 1 ? x6c_tps1() : 3;
+  const size_t lds = x6c_lds_bytes(g.CSl, tv.TM, tps);
   const int post_act = (pk.ksplit > 1 && g.act_epi != P2I_ACT_NONE) ? g.act_epi : P2I_ACT_NONE;
   const float* post_res = nullptr;
   if (pk.ksplit > 1) {       // partial sums are added: start from zero (stream-ordered in front of the kernel)
@@ -605,6 +636,7 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   k.sdt1 = ns > 1 ? cs.dt[9] : 0; k.swt1 = ns > 1 ? cs.tw[9] - cs.tw[0] : 0;
   k.sdt2 = ns > 2 ? cs.dt[18] : 0; k.swt2 = ns > 2 ? cs.tw[18] - cs.tw[0] : 0;
   if (tv.TM == 2) x6c_launch<8, 2>(k, grid, lds, s);
+  else if (tps == 9) x6c_launch<8, 1, false, 9>(k, grid, lds, s);
   else x6c_launch<8, 1>(k, grid, lds, s);
   if (post_act != P2I_ACT_NONE) {
     const long long n4 = n_dst / 4;
@@ -689,9 +721,11 @@ int run_patch_gemm_x6c_fused(PatchGeom g, const ClassSpec* css, int ncls, const 
   }
   if (ksplit > 1 && hipMemsetAsync(g.dst, 0, sizeof(float) * (size_t)n_dst, s) != hipSuccess) return P2I_EINVAL;
   const dim3 grid((unsigned)(ceil_div((int)nimg, jb) * k.nth * k.ntw), (unsigned)ceil_div(g.Cm, 32), (unsigned)ksplit);
-  const size_t lds = sizeof(float) * (size_t)((k.CSl + 3) & ~3) + 16 * (size_t)(6 * 18 * 32 + 2 * 6 * k.CSl);
+  const int tps = x6c_tps1();
+  const size_t lds = x6c_lds_bytes(k.CSl, 1, tps);
   if (plan6) { plan6[0] = 32; plan6[1] = 256; plan6[2] = ksplit; plan6[3] = 16; plan6[4] = 9; plan6[5] = 8; }
-  x6c_launch<8, 1, true>(k, grid, lds, s);
+  if (tps == 9) x6c_launch<8, 1, true, 9>(k, grid, lds, s);
+  else x6c_launch<8, 1, true>(k, grid, lds, s);
   return launch_status();
 }
 
