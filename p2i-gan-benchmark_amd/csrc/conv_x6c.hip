@@ -95,6 +95,7 @@ struct X6cGeom {
   int tap_off[9];
   int tap_w[9];
   int fused_atomic;     // FUSED kernels with split-K: the class pairs are ADDED to a zeroed destination
+  int stagger;          // waves 4-7 (the SIMD partners of waves 0-3) run a stage's staging work AFTER its first taps instead of before
 };
 
 // FUSED (data gradient of a stride-(.,2,2) 3x3 convolution: conv_fused.hip on the bf16 matrix pipe): the nine taps of a chunk belong
@@ -245,6 +246,14 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
     }
   };
   auto split_patch = [&](u32x4c* pb) {
+    // The loaded values become visible to the compiler HERE (the counted wait is in front of every call): an empty asm redefines
+    // each register, so that nothing computed from pv can be hoisted above the wait.  Needed since the split pass exists at several
+    // sites of the loop (staggered halves): hipcc merged the sites' common subexpressions and evaluated them right behind the
+    // asm loads, before the data had landed (wrong results in the first staggered build).
+#pragma unroll
+    for (int it = 0; it < NI; ++it)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(pv[it][q]));
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
       if (it_dst[it] < 0) continue;
@@ -348,6 +357,8 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
 #ifdef P2I_STAMP
   X6C_NOW(st_loop0); st_prev = st_loop0;
 #endif
+  const bool late = g.stagger > 0 && wave >= NW / 2;     // wave-uniform (wave is a readfirstlane value)
+  const int split_t = g.stagger > 0 ? (late ? 7 : 4) : 6; // whole-chunk stages: tap in front of which this wave runs its split pass
   int s = 0;
   for (int c = 0; c < nch; ++c) {
     const u32x4c* pb = planes + (c & 1) * PST + lane_base;
@@ -356,25 +367,33 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
 #pragma unroll
     for (int b = 0; b < NSTG; ++b, ++s) {
       const int sa = s + LEAD;
-      if (b == 0 && more_c) load_patch(c + 1);
-      if constexpr (TPS == 3) {
-        if (b == 2 && more_c) {
-          // patch loads were issued in stage s-2; younger: the weights issued in stages s-2 and s-1
-          x6c_wait_vm(nwb(s - 2 + LEAD) + nwb(s - 1 + LEAD));
-          __builtin_amdgcn_sched_barrier(0);
-          split_patch(planes + ((c + 1) & 1) * PST);     // buffer read last in chunk c-1
+      // Staging work of the stage (next chunk's patch loads, the split pass, the weight DMAs of stage s+LEAD).  The two waves of a SIMD
+      // (w and w + 4) run the same program between the same barriers: in lockstep both stage first (matrix pipe idle) and then
+      // both multiply (VALU idle).  With `stagger` waves 4-7 do their staging work AFTER the stage's first taps, so one wave's
+      // VALU / VMEM / LDS-write work runs under its partner's MFMAs.  The ORDER of this wave's vector-memory operations and of its
+      // counted waits is the same in both placements, so the vmcnt arithmetic below holds for both.
+      auto staging = [&]() {
+        if (b == 0 && more_c) load_patch(c + 1);
+        if constexpr (TPS == 3) {
+          if (b == 2 && more_c) {
+            // patch loads were issued in stage s-2; younger: the weights issued in stages s-2 and s-1
+            x6c_wait_vm(nwb(s - 2 + LEAD) + nwb(s - 1 + LEAD));
+            __builtin_amdgcn_sched_barrier(0);
+            split_patch(planes + ((c + 1) & 1) * PST);     // buffer read last in chunk c-1
+          }
         }
-      }
-      if (sa < nst) issue_w(c + (b + LEAD) / NSTG, (b + LEAD) % NSTG, sa % RING);   // slot read last in stage s-1 (complete before its barrier)
+        if (sa < nst) issue_w(c + (b + LEAD) / NSTG, (b + LEAD) % NSTG, sa % RING);   // slot read last in stage s-1 (complete before its barrier)
+      };
+      if (TPS == 9 || !late) staging();
       X6C_ACC(st_issue, st_prev);                                  // patch loads / split pass / weight DMA issue
       const u32x4c* wsl = wlane + (s % RING) * WST;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < TPS - 1; ++t) {
         if constexpr (TPS == 9) {
-          if (t == 6 && more_c) {
-            // whole-chunk stage: the patch loads went out at the top of THIS stage, six taps of MFMAs ago; younger: only this
-            // stage's weight batch.  (The wait also retires the weights of stage s+1, issued a stage earlier.)
+          // whole-chunk stage: the patch loads went out at the top of THIS stage; younger: only this stage's weight batch (the wait
+          // also retires the weights of stage s+1, issued a stage earlier).  Split pass after four taps, or after seven (staggered half).
+          if (more_c && (t == 4 || t == 6 || t == 7) && t == split_t) {
             x6c_wait_vm(nwb(sa));
             __builtin_amdgcn_sched_barrier(0);
             split_patch(planes + ((c + 1) & 1) * PST);   // buffer read last in chunk c-1
@@ -386,6 +405,7 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
         ilv();
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (TPS == 3 && late) { staging(); __builtin_amdgcn_sched_barrier(0); }
       X6C_ACC(st_mfma, st_prev);
       // stage s+1 needs its weights W(s+1); everything issued after that batch may stay in flight: W(s+2) .. W(s+LEAD), and the
       // patch loads of the stages s+2-LEAD .. s that start a chunk (kernel-row stages only: a whole-chunk stage has split its
@@ -459,6 +479,10 @@ static int x6c_min_wg() { const char* e = getenv("P2I_X6C_MIN_WG"); return e ? a
 // P2I_X6C_TILE=<NW><TM> (82, 81) forces one variant (tests, tuning)
 static int x6c_forced() { const char* e = getenv("P2I_X6C_TILE"); return e ? atoi(e) : 0; }
 
+// P2I_X6C_STAGGER=1: waves 4-7 run their staging work late in the stage (see `staging` in the kernel).  Measured in round 3 at B = 8
+// (gpurun_out/r03d/s0.log vs s1.log): no gain -- 64-channel level 75.0 -> 74.3 / 76.1 -> 81.2 us, every other layer within 1 us -- so
+// the lockstep schedule stays the default; read per call (A/B runs)
+static int x6c_stagger() { const char* e = getenv("P2I_X6C_STAGGER"); return e ? atoi(e) : 0; }
 static int x6c_fused_ksplit() { const char* e = getenv("P2I_X6C_FUSED_KSPLIT"); return e ? atoi(e) : 0; }   // read per call (tests)
 
 struct X6cVariant { int NW, TM; };
@@ -632,6 +656,7 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   k.nth = g.nth; k.ntw = g.ntw; k.mg_ew = g.mg_ew; k.mg_eh = g.mg_eh; k.ntaps_w = g.ntaps_w; k.ksplit = g.ksplit;
   for (int i = 0; i < 9; ++i) { k.tap_off[i] = g.tap_off[i]; k.tap_w[i] = g.tap_w[i]; }
   k.sT = g.sT; k.nT = g.nT; k.mT = g.mT; k.oT = g.oT; k.pT = g.pT; k.ns = ns;
+  k.stagger = x6c_stagger();
   k.sdt0 = cs.dt[0]; k.swt0 = 0;
   k.sdt1 = ns > 1 ? cs.dt[9] : 0; k.swt1 = ns > 1 ? cs.tw[9] - cs.tw[0] : 0;
   k.sdt2 = ns > 2 ? cs.dt[18] : 0; k.swt2 = ns > 2 ? cs.tw[18] - cs.tw[0] : 0;
@@ -712,7 +737,7 @@ int run_patch_gemm_x6c_fused(PatchGeom g, const ClassSpec* css, int ncls, const 
   k.eH = jh + 1; k.eW = jw + 1; k.CSl = csl; k.bH = 0; k.bW = 0;
   k.nth = ceil_div(c0.nH, jh); k.ntw = ceil_div(c0.nW, jw);
   k.mg_ew = magic_u16(k.eW); k.mg_eh = magic_u16(k.eH);
-  k.ntaps_w = ntaps_w; k.ksplit = ksplit; k.fused_atomic = ksplit > 1 ? 1 : 0;
+  k.ntaps_w = ntaps_w; k.ksplit = ksplit; k.fused_atomic = ksplit > 1 ? 1 : 0; k.stagger = x6c_stagger();
   k.sT = g.sT; k.nT = c0.nT; k.mT = 1; k.oT = c0.oT; k.pT = c0.pT; k.ns = ns;
   k.sdt0 = sdt[0]; k.sdt1 = sdt[1]; k.sdt2 = sdt[2]; k.swt0 = swt[0]; k.swt1 = swt[1]; k.swt2 = swt[2];
   for (int sl = 0; sl < 9; ++sl) {
