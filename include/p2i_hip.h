@@ -102,6 +102,10 @@ int p2i_conv_dgrad_x6(const p2i_conv_desc* d, const float* dy, const float* wp_d
  * stacks no layer needs.  Layers with too few output tiles for 256 CUs whose epilogue is linear (no activation) run with the channel
  * chunks split over two workgroups per tile that add their partial sums into the zeroed destination (P2I_X6C_KSPLIT=0 disables). */
 int p2i_x6_split(const float* wp, uint16_t* wb, int ntaps, int K, int Mpad, void* stream);
+/* the same for n <= 24 packed tensors of different shapes in one launch (wb[i]: 3 * ntaps[i] * K[i] * Mpad[i] uint16 each): the
+ * discriminators' layers after p2i_weight_pack_batched */
+int p2i_x6_split_batched(const float* const* wp, uint16_t* const* wb, const int* ntaps, const int* K, const int* Mpad, int n,
+                         void* stream);
 int p2i_x6c_would_take(const p2i_conv_desc* d, int dgrad, int act);
 int p2i_conv_fwd_x6s(const p2i_conv_desc* d, const float* x, const float* wp, const uint16_t* wb_layer, int ntaps_w,
                      const float* bias, const float* residual, float* y, int act, void* stream);

@@ -66,6 +66,31 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ w
   }
 }
 
+// wsplit_kernel for up to 24 packed tensors of DIFFERENT shapes in one launch (the discriminators' layers after a weight pack:
+// blockIdx.y = tensor); same images as x6_split_weights
+struct WsplitBatch { const float* wp[24]; u32x4c* wb[24]; int ntaps[24], Ck[24], CmPad[24]; };
+__global__ __launch_bounds__(256) void wsplit_batched_kernel(const WsplitBatch b) {
+  const int L = blockIdx.y;
+  const float* wp = b.wp[L];
+  u32x4c* wb = b.wb[L];
+  const int Ck = b.Ck[L], CmPad = b.CmPad[L], KCt = Ck >> 3;
+  const int total = b.ntaps[L] * KCt * CmPad;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int m = i % CmPad;
+    const int r = i / CmPad;
+    const int kc = r % KCt, tap = r / KCt;
+    const float* p = wp + ((size_t)tap * Ck + kc * 8) * CmPad + m;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = p[(size_t)q * CmPad];
+    u32x4c h, mi, lo;
+    split8c(v, h, mi, lo);
+    wb[i] = h;
+    wb[total + i] = mi;
+    wb[2 * total + i] = lo;
+  }
+}
+
 X6Ctx& x6_ctx() {
   static thread_local X6Ctx c{nullptr, 0};
   return c;
@@ -755,3 +780,20 @@ int run_patch_gemm_x6c_fused(PatchGeom g, const ClassSpec* css, int ncls, const 
 }
 
 }  // namespace p2i
+
+extern "C" int p2i_x6_split_batched(const float* const* wp, uint16_t* const* wb, const int* ntaps, const int* K, const int* Mpad, int n,
+                                    void* stream) {
+  using namespace p2i;
+  P2I_REQUIRE(wp && wb && ntaps && K && Mpad && n >= 1 && n <= 24, "p2i_x6_split_batched: 1..24 tensors");
+  WsplitBatch b{};
+  int maxn = 0;
+  for (int i = 0; i < n; ++i) {
+    P2I_REQUIRE(wp[i] && wb[i] && ntaps[i] > 0 && K[i] > 0 && (K[i] & 7) == 0 && Mpad[i] > 0 && (Mpad[i] & 31) == 0, "p2i_x6_split_batched: bad tensor %d", i);
+    b.wp[i] = wp[i]; b.wb[i] = reinterpret_cast<u32x4c*>(wb[i]); b.ntaps[i] = ntaps[i]; b.Ck[i] = K[i]; b.CmPad[i] = Mpad[i];
+    const int tot = ntaps[i] * (K[i] >> 3) * Mpad[i];
+    if (tot > maxn) maxn = tot;
+  }
+  const int blocks = (maxn + 255) / 256;
+  hipLaunchKernelGGL(wsplit_batched_kernel, dim3(blocks > 1024 ? 1024 : blocks, n), dim3(256), 0, (hipStream_t)stream, b);
+  return launch_status();
+}

@@ -35,6 +35,7 @@ SIGNATURES = {
     "p2i_conv_fwd_x6": [_D, _P, _P, _P, _P, _P, _P, _I, _P],
     "p2i_conv_dgrad_x6": [_D, _P, _P, _P, _P, _P, _I, _P, _P],
     "p2i_x6_split": [_P, _P, _I, _I, _I, _P],
+    "p2i_x6_split_batched": [_P, _P, _P, _P, _P, _I, _P],
     "p2i_x6c_would_take": [_D, _I, _I],
     "p2i_conv_fwd_x6s": [_D, _P, _P, _P, _I, _P, _P, _P, _I, _P],
     "p2i_conv_dgrad_x6s": [_D, _P, _P, _P, _I, _P, _P, _I, _P, _P],

@@ -240,7 +240,8 @@ class TrainEngine:
 
     def _step_impl(self, frames, masked, masks) -> Dict[str, torch.Tensor]:
         if self.direct:
-            return self._step_direct(frames, masked, masks)
+            with ops.step_stream():                     # one stream look-up per step instead of one per launch
+                return self._step_direct(frames, masked, masks)
         self._mark()
         self.G.train()
         preds = self.G(masked, masks)

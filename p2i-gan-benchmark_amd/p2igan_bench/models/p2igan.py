@@ -10,6 +10,7 @@ keeps the activations it needs for the hand-written backward.
 from __future__ import annotations
 
 import math
+import os
 from typing import List
 
 import torch
@@ -468,6 +469,7 @@ class P2IDiscriminator(nn.Module):
         self.alpha3d = nn.Parameter(torch.tensor(0.0))      # declared but unused by forward (p2igan.py:145,170)
         self.debug_taps = None
         self._pack_pool, self._pack_turn = {}, 0            # reusable packed-weight buffers (discriminator_forward)
+        self._x6_wants = {}                                 # (input dims, ...) -> which packed tensors the split-pipe kernels will take
         if init_weights:
             self.init_weights()
         self.specs2d, cin = [], in_channels
@@ -486,6 +488,21 @@ class P2IDiscriminator(nn.Module):
                 init.kaiming_normal_(m.weight_orig.data, a=0.2, nonlinearity="leaky_relu")
                 if m.bias is not None:
                     init.zeros_(m.bias)
+
+    def _layer_in_dims(self, b, cin0, t, h, w, spec):
+        """(T, H, W) of the INPUT of layer `spec` for a (b, t, 1, h, w) clip (2-D branch: frames are channels, T = 1)."""
+        if spec in self.specs2d:
+            dims = (1, h, w)
+            for sp in self.specs2d:
+                if sp is spec:
+                    return dims
+                dims = sp.out_dims(*dims)
+        dims = (t, h, w)
+        for sp in self.specs3d:
+            if sp is spec:
+                return dims
+            dims = sp.out_dims(*dims)
+        raise RuntimeError("layer not found")
 
     def layers(self):
         l2 = [self.d2d[i] for i, _, _ in D2D_LAYERS]
@@ -535,6 +552,23 @@ def discriminator_forward(net: "P2IDiscriminator", x, need_x: bool, need_p: bool
         pbuf = bufs[net._pack_turn]
     packed = ops.weight_pack_batched(wflats, sig_all, need_d=need_d, buf=pbuf)
     pack_of = {id(m): pk for m, pk in zip(l2 + l3, packed)}
+    # bf16 split of every packed tensor a conv call of this pass (forward now, data gradient later) will take on the split pipe:
+    # one launch for all of them instead of one per call
+    wkey = (b, t, h, w, need_d, ops.CONV_ENGINE, os.environ.get("P2I_X6C_MIN_WG"))
+    wants = net._x6_wants.get(wkey)
+    if wants is None:
+        wants = []
+        for spec in net.specs2d + net.specs3d:
+            dsc = spec.desc(b, *net._layer_in_dims(b, None, t, h, w, spec))
+            wants += [spec.cin % 16 == 0 and bool(ops._hip.load().p2i_x6c_would_take(dsc, 0, ACT_LEAKY)),
+                      need_d and spec.cout % 16 == 0 and spec.cin > 1 and bool(ops._hip.load().p2i_x6c_would_take(dsc, 1, ACT_NONE))]
+        net._x6_wants[wkey] = wants
+    tens = [t_ for pk in packed for t_ in pk]
+    if pool:
+        sb = net._pack_pool.setdefault(("x6", need_d, str(xin.device)), [None] * 4)
+        sb[net._pack_turn] = ops.x6_presplit(tens, wants, buf=sb[net._pack_turn])
+    else:
+        ops.x6_presplit(tens, wants)
 
     def branch(layers, specs, inp):
         recs, cur = [], inp

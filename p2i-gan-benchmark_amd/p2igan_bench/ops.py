@@ -19,8 +19,28 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# HIP stream handle of the calling step.  torch.cuda.current_stream() costs ~1.5 us and a train step asks ~800 times; TrainEngine
+# pins the handle for the duration of a step (step_stream), SideStream.run swaps in its own.  None: ask torch (every other caller).
+_CUR_STREAM = None
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _CUR_STREAM if _CUR_STREAM is not None else torch.cuda.current_stream().cuda_stream
+
+
+class step_stream:
+    """with ops.step_stream(): ...  -- every op inside enqueues on the stream that is current at entry."""
+
+    def __enter__(self):
+        global _CUR_STREAM
+        self.prev = _CUR_STREAM
+        _CUR_STREAM = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        global _CUR_STREAM
+        _CUR_STREAM = self.prev
+        return False
 
 
 def _chk(*ts):
@@ -141,6 +161,45 @@ class X6Stack:
                 v._x6s = (st, i)
 
 
+class _X6One:
+    """One tensor's pre-split image (see x6_presplit): quacks like an X6Stack of a single layer."""
+
+    def __init__(self, ptr, taps):
+        self.ptr, self.n, self.taps = ptr, 1, taps
+
+    def layer_ptr(self, i):
+        return self.ptr
+
+
+def x6_presplit(tensors, wants, buf=None):
+    """bf16 split of several packed weight tensors of DIFFERENT shapes in ONE launch (p2i_x6_split_batched) -- the discriminators'
+    layers right after weight_pack_batched; `wants[i]` says whether any conv call of the coming pass would use tensor i's split
+    (p2i_x6c_would_take).  Attaches `_x6s` to the tensors like X6Stack.attach does, so that conv_fwd / conv_dgrad skip their
+    per-call split (18 launches of ~7 us per train step before).  buf: caller-owned int16 buffer to reuse.  Returns the buffer."""
+    if CONV_ENGINE not in ("auto", "x6"):
+        return buf
+    sel = [t for t, w in zip(tensors, wants) if w and t is not None and t.shape[1] % 16 == 0]
+    if not sel:
+        return buf
+    import ctypes
+    need = sum(3 * t.numel() for t in sel)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, device=sel[0].device, dtype=torch.int16)
+    n = len(sel)
+    ptrs, off = [], 0
+    for t in sel:
+        ptrs.append(buf.data_ptr() + 2 * off)
+        off += 3 * t.numel()
+    arr_i = ctypes.c_int * n
+    _hip.check(_hip.load().p2i_x6_split_batched(_ptr_array(sel), (ctypes.c_void_p * n)(*ptrs), arr_i(*[t.shape[0] for t in sel]),
+                                                arr_i(*[t.shape[1] for t in sel]), arr_i(*[t.shape[2] for t in sel]), n, _stream()),
+               "p2i_x6_split_batched")
+    for t, p_ in zip(sel, ptrs):
+        t._x6s = (_X6One(p_, t.shape[0]), 0)
+        t._x6buf = buf                       # keeps the image alive as long as the packed tensor
+    return buf
+
+
 def _x6s_of(wp, d, dgrad, act=ACT_NONE):
     """(layer pointer, total taps) of a pre-split stack when this call would run on the bf16-split kernel, else None."""
     h = getattr(wp, "_x6s", None)
@@ -183,8 +242,13 @@ class SideStream:
         ev = torch.cuda.Event()
         ev.record()                                    # everything enqueued on the main stream so far (producers of `tensors`)
         self.stream.wait_event(ev)
-        with torch.cuda.stream(self.stream):
-            out = fn()
+        global _CUR_STREAM
+        prev, _CUR_STREAM = _CUR_STREAM, self.stream.cuda_stream
+        try:
+            with torch.cuda.stream(self.stream):
+                out = fn()
+        finally:
+            _CUR_STREAM = prev
         self.keep.extend(tensors)
         self.pending = True
         return out
@@ -219,14 +283,23 @@ class ConvSpec:
         return tuple((d + 2 * p - k) // s + 1 for d, p, k, s in zip((t, h, w), self.pad, self.k, self.stride))
 
     def desc(self, b, t, h, w) -> ConvDesc:
-        to, ho, wo = self.out_dims(t, h, w)
-        return ConvDesc(b, self.cin, self.cout, t, h, w, to, ho, wo, *self.k, *self.stride, *self.pad)
+        return _conv_desc(self, b, t, h, w)
 
     def wp_f_shape(self):
         return (self.ntaps, self.cin, pad32(self.cout))
 
     def wp_d_shape(self):
         return (self.ntaps, self.cout, pad32(self.cin))
+
+
+import functools
+
+
+@functools.lru_cache(maxsize=512)
+def _conv_desc(spec: ConvSpec, b, t, h, w) -> ConvDesc:
+    """The (read-only) descriptor of one layer at one input size: built once, ~3 us of ctypes work per call otherwise."""
+    to, ho, wo = spec.out_dims(t, h, w)
+    return ConvDesc(b, spec.cin, spec.cout, t, h, w, to, ho, wo, *spec.k, *spec.stride, *spec.pad)
 
 
 def _dims5(x: torch.Tensor):
