@@ -13,7 +13,15 @@
  *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*), never syncs;
  *  - state kept by the library: none that a result depends on.  Per calling THREAD it remembers the tile plan of the last
  *    conv / wgrad launch (p2i_conv_last_plan / p2i_wgrad_last_plan, diagnostics) and the scratch pointers of a running
- *    p2i_conv_*_x6 / p2i_conv_wgrad_ws call; tuning switches (P2I_* environment variables) are read once per process;
+ *    p2i_conv_*_x6 / p2i_conv_wgrad_ws call.  Tuning switches (P2I_* environment variables): the engine on/off switches
+ *    (P2I_CONV_X6C, P2I_CONV_X6C_FUSED, P2I_X6C_KSPLIT, P2I_CONV_V4, P2I_CONV_CK16, P2I_CONV_KG27, P2I_DGRAD_FUSED, P2I_DGRAD_PAIR,
+ *    P2I_C1_FAST, P2I_O1_FWD, P2I_WGRAD_X4, P2I_WGRAD_WINDOW) are read ONCE per process; the per-launch choices that the parity
+ *    tests flip inside one process (P2I_X6C_MIN_WG, P2I_X6C_TILE, P2I_X6C_TPS, P2I_X6C_STAGGER, P2I_X6C_FUSED_KSPLIT, P2I_WGRAD_X6)
+ *    are read on EVERY call;
+ *  - aliasing: an output may alias the epilogue operand of the same call that is read element-for-element at the position it is
+ *    written (y == residual, dx == dx_add, dx == mask_y): every kernel reads it before it writes that element, and the split-K
+ *    launches of the bf16-split kernels (which zero-fill the destination first) are not chosen for an aliased call.  No other
+ *    overlap between inputs and outputs is allowed;
  *  - return value: 0 on success, negative P2I_E* on a rejected argument, positive = hipError_t
  *    of a failed launch.  Nothing throws across the ABI;
  *  - activations are NC(T)HW; a 2-D tensor is the T == 1 case of the 5-D one.
@@ -76,17 +84,24 @@ int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, cons
  * (<= 256 * kh*kw * Cin * pad32(Cout) floats, 37.7 MB for the generator's 3x3 C->C layers) the partial tiles are stored
  * and summed by a second kernel instead of being added with float atomics: faster, and bit-reproducible.  ws == NULL or
  * too small: the atomic path of p2i_conv_wgrad.
- * With a sufficient scratch, 3x3 stride-1 pad-1 2-D layers whose Cin and Cout are multiples of 64, Ho % 4 == 0, Wo % 16 == 0,
- * called without act'(y) prologue and without dbias (the generator's DO-Conv stack) are computed on the bf16 matrix pipe with fp32
- * accuracy (wgrad_x6.hip: x and dy split exactly into three bf16 terms each, six MFMA products per fp32 product, transposed
- * LDS reads); same result contract, same slices + reduce.  P2I_WGRAD_X6=0 keeps the fp32-MFMA kernel. */
+ * With a sufficient scratch, 3x3 pad-1 2-D layers and 3x3x3 pad-1 layers with t stride <= 2 (three t slices), spatial stride 1,
+ * whose Cin and Cout are multiples of 64, Ho % 4 == 0, Wo % 16 == 0, called without act'(y) prologue (the generator's DO-Conv stack,
+ * the discriminators' 256 -> 256 and 128 -> 128 layers) are computed on the bf16 matrix pipe with fp32 accuracy (wgrad_x6.hip: x
+ * and dy split exactly into three bf16 terms each, six MFMA products per fp32 product, transposed LDS reads), dbias included
+ * (summed from the staged dy tiles, added atomically); same result contract, same slices + reduce.  P2I_WGRAD_X6=0 (read per
+ * call) keeps the fp32-MFMA kernel. */
 int p2i_conv_wgrad_ws(const p2i_conv_desc* d, const float* x, const float* dy, const float* y_act, int act, float* dwp,
                       float* dbias, float* ws, int64_t ws_floats, void* stream);
-/* Same contracts as p2i_conv_fwd / p2i_conv_dgrad (without the act'(y) prologue).  3x3 stride-1 2-D layers with a contraction
- * width K % 16 == 0 and enough output tiles to fill the chip are computed on the bf16 matrix pipe with fp32 accuracy
- * (conv_x6c.hip): every fp32 operand is split exactly into three bf16 terms and six v_mfma_f32_32x32x16_bf16 products are
- * accumulated in fp32 (the dropped products are <= 2^-23 |a b| each, below the rounding of an fp32 fma chain).  Every other
- * layer runs on the fp32-MFMA kernels, exactly as p2i_conv_fwd / p2i_conv_dgrad would; the choice is the library's.
+/* Same contracts as p2i_conv_fwd / p2i_conv_dgrad (without the act'(y) prologue).  With a contraction width K % 16 == 0 and
+ * enough output tiles to fill the chip, these layers are computed on the bf16 matrix pipe with fp32 accuracy (conv_x6c.hip):
+ *   - 3x3 stride-1 pad-1 2-D layers, forward and data gradient;
+ *   - 3x3x3 pad-1 layers with spatial stride 1 and t stride 1 or 2 (the 27 taps as three t slices of nine), forward and data
+ *     gradient (one launch per t-parity class);
+ *   - the data gradient of 3x3 / 3x3x3 layers with stride (1,2,2) and even input height / width: the four input-parity classes
+ *     of the destination fused in one workgroup (patch_gemm_x6c_kernel<8,1,true,.>).
+ * Every fp32 operand is split exactly into three bf16 terms and six v_mfma_f32_32x32x16_bf16 products are accumulated in fp32
+ * (the dropped products are <= 2^-23 |a b| each, below the rounding of an fp32 fma chain).  Every other layer runs on the
+ * fp32-MFMA kernels, exactly as p2i_conv_fwd / p2i_conv_dgrad would; the choice is the library's.
  * `wsplit`: caller-owned scratch of 3*ntaps*K*pad32(M) uint16 (K = contraction channels: Cin for fwd, Cout for dgrad; M the
  * other one), overwritten by the call; wsplit == NULL forces the fp32-MFMA kernels.  P2I_X6C_MIN_WG (read per call) overrides
  * the tile-count threshold (default 200 workgroups of 64 x 256 outputs). */
@@ -113,11 +128,14 @@ int p2i_conv_dgrad_x6s(const p2i_conv_desc* d, const float* dy, const float* wp_
                        const float* dx_add, const float* mask_y, int mask_act, float* dx, void* stream);
 /* tile plan {MB, NPIX, WAVES_M, CK, NT, KG} of the calling thread's most recent fwd/dgrad launch: names the
  * patch_gemm_dma_kernel<MB,NPIX,WAVES_M,CK,NT,KG> instance (NT = -1: the prologue kernel
- * patch_gemm_kernel<MB,NPIX,WAVES_M,CK>; KG = 7: patch_gemm_x6c_kernel, fields {64,256,1,16,9,7})
+ * patch_gemm_kernel<MB,NPIX,WAVES_M,CK>; KG = 7: patch_gemm_x6c_kernel<8, MB/32, false, TPS>, fields {MB = 32 or 64, 256, ksplit,
+ * 16, TPS = taps per pipeline stage (3 or 9), 7}; KG = 8: the fused strided data gradient patch_gemm_x6c_kernel<8, 1, true, TPS>,
+ * fields {32, 256, ksplit, 16, TPS, 8}; KG = 3: o1_fwd_kernel (single output channel), fields {1, 64, 8, 1, 9, 3}; KG > 10: the f32
+ * fused strided data gradient patch_gemm_fused_kernel with KG - 10 parity classes per workgroup)
  * so that bench.py's roofline can be matched to rocprofv3 rows */
 int p2i_conv_last_plan(int* out6);
 /* same for the most recent p2i_conv_wgrad: {kind (0 wgrad_kernel<64>, 1 wgrad_dma_kernel<64,NTAP,Y4,CB>, 2 c1_wgrad_kernel,
- * 3 wgrad_x6_kernel), NTAP, Y4, CB} */
+ * 3 wgrad_x6_kernel), NTAP (wgrad_x6: 9 * kt taps in one launch), Y4, CB} */
 int p2i_wgrad_last_plan(int* out4);
 
 /* ------------------------------------------------------------------ weight preparation

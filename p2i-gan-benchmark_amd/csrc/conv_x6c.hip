@@ -671,7 +671,7 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
     if (hipMemsetAsync(g.dst, 0, sizeof(float) * (size_t)n_dst, s) != hipSuccess) return P2I_EINVAL;
     if (post_act != P2I_ACT_NONE) { post_res = g.res; g.res = nullptr; g.act_epi = P2I_ACT_NONE; }   // act(sum + bias) + res: second pass
   }
-  if (plan6) { plan6[0] = 32 * tv.TM; plan6[1] = 32 * tv.NW; plan6[2] = pk.ksplit; plan6[3] = 16; plan6[4] = 9; plan6[5] = 7; }
+  if (plan6) { plan6[0] = 32 * tv.TM; plan6[1] = 32 * tv.NW; plan6[2] = pk.ksplit; plan6[3] = 16; plan6[4] = tps; plan6[5] = 7; }
   X6cGeom k{};
   k.src = g.src; k.dst = g.dst; k.wb = g.wb; k.bias = g.bias; k.res = g.res; k.mask_y = g.mask_y;
   k.wb_bytes = g.wb_bytes; k.act_epi = g.act_epi; k.mask_act = g.mask_act;
@@ -773,7 +773,7 @@ int run_patch_gemm_x6c_fused(PatchGeom g, const ClassSpec* css, int ncls, const 
   const dim3 grid((unsigned)(ceil_div((int)nimg, jb) * k.nth * k.ntw), (unsigned)ceil_div(g.Cm, 32), (unsigned)ksplit);
   const int tps = x6c_tps1();
   const size_t lds = x6c_lds_bytes(k.CSl, 1, tps);
-  if (plan6) { plan6[0] = 32; plan6[1] = 256; plan6[2] = ksplit; plan6[3] = 16; plan6[4] = 9; plan6[5] = 8; }
+  if (plan6) { plan6[0] = 32; plan6[1] = 256; plan6[2] = ksplit; plan6[3] = 16; plan6[4] = tps; plan6[5] = 8; }
   if (tps == 9) x6c_launch<8, 1, true, 9>(k, grid, lds, s);
   else x6c_launch<8, 1, true>(k, grid, lds, s);
   return launch_status();

@@ -102,11 +102,12 @@ def _prof_end(e0, kind, spec, desc, stride1):
         if plan[5] > 10:
             key = "patch_gemm_fused_kernel<%d, %d, %d, %d, %d> (strided dgrad, %d parity classes per workgroup)" % (plan[0], plan[1], plan[2], plan[3], plan[5] - 10, plan[5] - 10)
         elif plan[5] == 7:
-            key = "patch_gemm_x6c_kernel<%d, %d> (%d x %d tile, bf16-split x6)" % (plan[1] // 32, plan[0] // 32, plan[0], plan[1])
+            key = "patch_gemm_x6c_kernel<%d, %d, false, %d> (%d x %d tile, %d taps per stage, bf16-split x6)" % (
+                plan[1] // 32, plan[0] // 32, plan[4], plan[0], plan[1], plan[4])
         elif plan[5] == 3:
             key = "o1_fwd_kernel (single output channel, bandwidth-bound)"
         elif plan[5] == 8:
-            key = "patch_gemm_x6c_kernel<8, 1, true> (strided dgrad, 4 parity classes per workgroup, bf16-split x6)"
+            key = "patch_gemm_x6c_kernel<8, 1, true, %d> (strided dgrad, 4 parity classes per workgroup, bf16-split x6)" % plan[4]
         else:
             key = "patch_gemm_dma_kernel<%d, %d, %d, %d, %d, %d>" % tuple(plan)
     PROFILE.records.append((key, flops, e0, e1))

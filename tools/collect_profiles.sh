@@ -2,7 +2,7 @@
 # Collects the round's judged artefacts on the GPU box into gpurun_out/<tag>/ (copy the summaries into profiles/ afterwards).
 # usage: bash tools/collect_profiles.sh <tag>      (every rocprofv3 run has python3 itself after "--"; PMC passes are separate runs)
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
