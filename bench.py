@@ -417,7 +417,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the conv-engine instance with the largest share of the step (single-kernel keys only)
         single = {k: v for k, v in summ.items()
-                  if (k.startswith(("patch_gemm_dma_kernel<", "wgrad_dma_kernel<")) and "(" not in k) or k.startswith(("patch_gemm_x6c_kernel<", "wgrad_x6_kernel"))}
+                  if (k.startswith(("patch_gemm_dma_kernel<", "wgrad_dma_kernel<")) and "(" not in k) or k.startswith(("patch_gemm_x6c_kernel<", "patch_gemm_x6p_kernel<", "wgrad_x6_kernel"))}
         dom = max(single, key=lambda k: single[k]["seconds"])
         d = single[dom]
         ach = d["flops"] / d["seconds"] / 1e12

@@ -498,6 +498,335 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// "x6p": the same tile, LDS images, weight ring and stage hand-over as patch_gemm_x6c_kernel, with the eight waves SPECIALISED:
+// waves 0-3 (one per SIMD) are CONSUMERS -- operand reads and MFMAs only, 32 TM channels x 64 positions each (two position blocks
+// share every weight operand: 0.625 / 0.75 reads per MFMA at TM 2 / 1) -- and waves 4-7 are PRODUCERS: the next chunk's patch loads,
+// the split pass and all weight DMAs.  A consumer's instruction stream never contains a vector-memory wait, a split pass or a DMA
+// issue; the producers' VALU / VMEM work runs on the same SIMDs beside the MFMAs and they park at the stage barrier when done.
+// Same numerics, same epilogue, same X6cGeom.
+template <int TM, int TPS, bool FUSED = false>
+__global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
+  constexpr int NSTG = 9 / TPS;
+  constexpr int NCLS = FUSED ? 4 : 1;                     // FUSED: see X6C_CLS (strided data gradient, four parity classes)
+  static_assert(TPS == 3 || TPS == 9, "taps per stage");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MB = 32 * TM, NTHR = 512, NPT = 256, NPW = 4;
+  constexpr int NI = (2 * X6cTile<8>::MAXCSL + NPT - 1) / NPT;            // patch items per producer thread: 3
+  constexpr int RING = TPS == 9 ? 3 : (TM == 2 ? 4 : 6), LEAD = RING - 1;
+  constexpr int WST = 6 * TPS * MB, NWI = WST / 64;
+  const int CSl = g.CSl;
+  int* ptab = reinterpret_cast<int*>(smem);
+  const int ptab_sz = (CSl + 3) & ~3;
+  u32x4c* wbuf = reinterpret_cast<u32x4c*>(smem + ptab_sz);
+  u32x4c* planes = wbuf + RING * WST;
+  const int PST = 6 * CSl;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int tile = blockIdx.x;
+  const int tw = tile % g.ntw; tile /= g.ntw;
+  const int th = tile % g.nth;
+  const int tb = tile / g.nth;
+  const int j0b = tb << g.ljb, j0h = th << g.ljh, j0w = tw << g.ljw;
+  const int o0 = blockIdx.y * MB;
+  const int JWm = (1 << g.ljw) - 1, JHm = (1 << g.ljh) - 1;
+  const int sHW = g.sH * g.sW;
+  const int src_h0 = j0h + g.bH, src_w0 = j0w + g.bW;
+  const int KCt = g.Ck >> 3;
+  const int cps = g.Ck >> 4;
+  const int cs = g.sT * sHW;
+  const int nimg = g.B * g.nT;
+  const int c0 = blockIdx.z * ((g.ns * cps) / g.ksplit);
+  const int nch = (g.ns * cps) / g.ksplit;
+  const int nst = NSTG * nch;
+
+  for (int e = tid; e < CSl; e += NTHR) {
+    const int row = fast_div(e, g.mg_ew);
+    const int ew = e - row * g.eW;
+    const int jb = fast_div(row, g.mg_eh);
+    const int eh = row - jb * g.eH;
+    const int n = j0b + jb, h = src_h0 + eh, w = src_w0 + ew;
+    const int b = n / g.nT, lt = n - b * g.nT;
+    ptab[e] = (n < nimg && (unsigned)h < (unsigned)g.sH && (unsigned)w < (unsigned)g.sW) ? ((b * g.Ck) * g.sT + lt * g.mT) * sHW + h * g.sW + w : -1;
+  }
+  __syncthreads();                                                        // ptab visible
+
+  if (wave >= NPW) {
+    // =============================================================== producers
+    const int ptid = tid - NPT, pw = wave - NPW;
+    const v4i32 rs_w = make_rsrc(g.wb, g.wb_bytes);
+    const unsigned wbuf_la = lds_base(smem) + 4u * ptab_sz;
+    const int wl_m = TM == 2 ? lane : l31, wl_kg = TM == 2 ? 0 : lhi;
+    const int wvoff = (o0 + wl_m < g.CmPad) ? (wl_kg * g.CmPad + wl_m) * 16 : -16;
+    int it_off[NI], it_dst[NI], it_f0[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int item = it * NPT + ptid;
+      const int kg = item >= CSl ? 1 : 0, e = item - kg * CSl;
+      const bool in = item < 2 * CSl;
+      const int po = in ? ptab[e] : -1;
+      it_off[it] = po < 0 ? -1 : po + kg * 8 * cs;
+      it_dst[it] = in ? kg * CSl + e : -1;
+      const int jbi = fast_div(fast_div(in ? e : 0, g.mg_ew), g.mg_eh);
+      it_f0[it] = ((j0b + jbi) % g.nT) * g.mT;
+    }
+    float pv[NI][8];
+    bool pok[NI];
+    auto load_patch = [&](int c) {
+      const int cg = c0 + c;
+      const int j = cg >= 2 * cps ? 2 : (cg >= cps ? 1 : 0);
+      const int dt = j == 2 ? g.sdt2 : (j == 1 ? g.sdt1 : g.sdt0);
+      const float* sc = g.src + (size_t)(cg - j * cps) * 16 * cs;
+      int voff[NI];
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        pok[it] = it_off[it] >= 0 && (unsigned)(it_f0[it] + dt) < (unsigned)g.sT;
+        voff[it] = pok[it] ? (it_off[it] + dt * sHW) * 4 : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float* sq = sc + (size_t)q * cs;
+        const unsigned long long sq_u = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)sq) & 0xffffffffull;
+        const unsigned long long sq_hi = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)sq >> 32));
+        const unsigned long long sbase = sq_u | (sq_hi << 32);
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+          if (it == 0) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(pv[it][q]) : "v"(voff[it]), "s"(sbase) : "memory");
+          else asm volatile("global_load_dword %0, %1, %2" : "=v"(pv[it][q]) : "v"(voff[it]), "s"(sbase) : "memory");
+        }
+      }
+    };
+    auto split_patch = [&](u32x4c* pb) {
+#pragma unroll
+      for (int it = 0; it < NI; ++it)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(pv[it][q]));     // values exist from here on (see patch_gemm_x6c_kernel)
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        if (it_dst[it] < 0) continue;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = pok[it] ? pv[it][q] : 0.f;
+        u32x4c h, mi, lo;
+        split8c(v, h, mi, lo);
+        pb[it_dst[it]] = h;
+        pb[2 * CSl + it_dst[it]] = mi;
+        pb[4 * CSl + it_dst[it]] = lo;
+      }
+    };
+    constexpr int NWR = (NWI + NPW - 1) / NPW;
+    int w_soff[NWR][NSTG];
+    unsigned w_dst[NWR];
+#pragma unroll
+    for (int r = 0; r < NWR; ++r) {
+      const int u = pw + NPW * r;
+      const int pt = TM == 2 ? u >> 1 : u, kg = TM == 2 ? u & 1 : 0;
+      const int p = pt / TPS, tl = pt % TPS;
+#pragma unroll
+      for (int b = 0; b < NSTG; ++b)
+        w_soff[r][b] = u < NWI ? __builtin_amdgcn_readfirstlane((((p * g.ntaps_w + g.tap_w[TPS * b + tl]) * KCt + kg) * g.CmPad + o0) * 16) : 0;
+      w_dst[r] = wbuf_la + 16u * (unsigned)(u * 64);
+    }
+    const int w_cstep = 2 * g.CmPad * 16;
+    const int w_tstep = KCt * g.CmPad * 16;
+    auto issue_w = [&](int c, int b, int sb) {
+      const int cg = c0 + c;
+      const int j = cg >= 2 * cps ? 2 : (cg >= cps ? 1 : 0);
+      const int soff = (cg - j * cps) * w_cstep + (j == 2 ? g.swt2 : (j == 1 ? g.swt1 : g.swt0)) * w_tstep;
+#pragma unroll
+      for (int r = 0; r < NWR; ++r)
+        if (pw + NPW * r < NWI) dma_b128(rs_w, w_dst[r] + 16u * (unsigned)(sb * WST), wvoff, w_soff[r][b] + soff);
+    };
+    const int nw_mine = (NWI / NPW) + (pw < NWI % NPW ? 1 : 0);
+    constexpr int NPL = 8 * NI;
+    auto nwb = [&](int st) { return st < nst ? nw_mine : 0; };
+    // vector-memory operations of a producer wave, in issue order: prologue [P(0)] [W(0)] .. [W(LEAD-1)]; per stage s:
+    // [P(chunk+1) if the stage starts a chunk that has a successor] [W(s+LEAD)]
+    load_patch(0);
+#pragma unroll
+    for (int st = 0; st < LEAD; ++st)
+      if (st < nst) issue_w(st / NSTG, st % NSTG, st % RING);
+    {
+      int n = 0;
+#pragma unroll
+      for (int st = 0; st < LEAD; ++st) n += nwb(st);
+      x6c_wait_vm(n);
+      __builtin_amdgcn_sched_barrier(0);
+      split_patch(planes);
+      x6c_wait_vm(n - nwb(0));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // hand-over of stage 0
+    int s = 0;
+    for (int c = 0; c < nch; ++c) {
+      const bool more_c = c + 1 < nch;
+#pragma unroll
+      for (int b = 0; b < NSTG; ++b, ++s) {
+        const int sa = s + LEAD;
+        if (b == 0 && more_c) load_patch(c + 1);
+        if (sa < nst) issue_w(c + (b + LEAD) / NSTG, (b + LEAD) % NSTG, sa % RING);   // slot read last in stage s-1
+        if (b == NSTG - 1 && more_c) {
+          // patch loads went out at the top of stage s - (NSTG - 1); younger: the weight batches of the stages since then
+          int n = 0;
+#pragma unroll
+          for (int j = 0; j < NSTG; ++j) n += nwb(sa - j);
+          x6c_wait_vm(n);
+          __builtin_amdgcn_sched_barrier(0);
+          split_patch(planes + ((c + 1) & 1) * PST);                     // buffer read last in chunk c-1
+        }
+        {
+          // stage s+1 needs W(s+1), issued at the top of stage s+1-LEAD.  Issued AFTER it (vmcnt counts in issue order, done or not):
+          // W(s+2) .. W(s+LEAD) and the patch loads at the tops of the stages s+2-LEAD .. s that start a chunk with a successor
+          int n = 0;
+#pragma unroll
+          for (int j = 2; j <= LEAD; ++j) n += nwb(s + j);
+#pragma unroll
+          for (int j = 0; j <= LEAD - 2; ++j) {
+            const int sj = s - j;
+            if (sj >= 0 && sj % NSTG == 0 && sj / NSTG + 1 < nch) n += NPL;
+          }
+          x6c_wait_vm(n);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // plane writes done
+        __builtin_amdgcn_s_barrier();                                     // hand-over of stage s+1
+      }
+    }
+  }
+
+  // ================================================================= consumers (producers only set up the epilogue geometry here)
+  const bool producer = wave >= NPW;
+  const int cw = wave & (NPW - 1);                                       // positions [64 cw, 64 cw + 64); producer w helps consumer w - 4
+  int lane_base[2], pjw_[2], pjh_[2], pjb_[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int pix = cw * 64 + nb * 32 + l31;
+    pjw_[nb] = pix & JWm; pjh_[nb] = (pix >> g.ljw) & JHm; pjb_[nb] = pix >> (g.ljw + g.ljh);
+    lane_base[nb] = (pjb_[nb] * g.eH + pjh_[nb]) * g.eW + pjw_[nb] + lhi * CSl;
+  }
+  int toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) toff[t] = g.tap_off[t];
+  f32x16 acc[NCLS][TM][2];
+#pragma unroll
+  for (int q = 0; q < NCLS; ++q)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][i][nb][r] = 0.f;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  u32x4c A[3][TM][3], Bv[3][2][3];
+  auto load_tap = [&](const u32x4c* wsl, const u32x4c* pbuf, int tap, int buf) {
+    const int tl = tap % TPS;
+    const int to = toff[tap];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) A[buf][i][p] = wsl[((p * TPS + tl) * 2) * MB + 32 * i];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) Bv[buf][nb][p] = pbuf[lane_base[nb] + p * 2 * CSl + to];
+    }
+  };
+  auto mfma_tap = [&](int buf, int slot) {
+    const int cl = FUSED ? X6C_CLS[slot] : 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          acc[cl][i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, A[buf][i][PA[q]]), __builtin_bit_cast(bf16x8c, Bv[buf][nb][PB[q]]),
+                                                                   acc[cl][i][nb], 0, 0, 0);
+  };
+  auto ilv = [&]() {
+    constexpr int NR = 3 * TM + 6, NM = 12 * TM;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+  };
+  const u32x4c* wlane = wbuf + lhi * MB + l31;
+  if (!producer) {
+    __builtin_amdgcn_s_barrier();                                         // stage 0 handed over by the producers
+    load_tap(wlane, planes, 0, 0);
+    int s = 0;
+    for (int c = 0; c < nch; ++c) {
+      const u32x4c* pb = planes + (c & 1) * PST;
+      const u32x4c* pbn = planes + ((c + 1) & 1) * PST;
+#pragma unroll
+      for (int b = 0; b < NSTG; ++b, ++s) {
+        const u32x4c* wsl = wlane + (s % RING) * WST;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TPS - 1; ++t) {
+          load_tap(wsl, pb, TPS * b + t + 1, (t + 1) % 3);
+          mfma_tap(t % 3, TPS * b + t);
+          ilv();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // own operand reads of this stage have returned
+        __builtin_amdgcn_s_barrier();                                     // stage s+1 handed over
+        if (s + 1 < nst) load_tap(wlane + ((s + 1) % RING) * WST, b == NSTG - 1 ? pbn : pb, b == NSTG - 1 ? 0 : TPS * b + TPS, 0);
+        mfma_tap(2, TPS * b + TPS - 1);
+        ilv();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // ---- epilogue, shared: the consumer keeps its first position block and parks the second one in LDS (every LDS image is dead
+  // now: all operand reads returned before the last stage barrier), its producer partner (same SIMD) picks it up, so that all
+  // eight waves load residual / mask values and store, as in the symmetric kernel
+  float* xch = reinterpret_cast<float*>(wbuf);                            // [4 consumers][NCLS][TM][16][64] floats <= 64 KB
+  if (!producer) {
+#pragma unroll
+    for (int q = 0; q < NCLS; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(((cw * NCLS + q) * TM + i) * 16 + r) * 64 + lane] = acc[q][i][1][r];
+  }
+  __syncthreads();
+  if (producer) {
+#pragma unroll
+    for (int q = 0; q < NCLS; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][i][1][r] = xch[(((cw * NCLS + q) * TM + i) * 16 + r) * 64 + lane];
+  }
+  const int dHW = g.dT * g.dH * g.dW;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    if ((nb == 1) != producer) continue;                                  // consumer: block 0, producer: block 1
+    const int gw = j0w + pjw_[nb], gh = j0h + pjh_[nb], gn = j0b + pjb_[nb];
+    const bool pvld = gn < nimg && gh < g.nH && gw < g.nW;
+    const int gb_ = gn / g.nT, glt = gn - gb_ * g.nT;
+    if constexpr (FUSED) {
+      const size_t pos0 = (size_t)gb_ * g.Cm * dHW + (size_t)(glt * g.oT + g.pT) * g.dH * g.dW + (size_t)(2 * gh) * g.dW + 2 * gw;
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          epilogue_pair16(acc[2 * ph][i][nb], acc[2 * ph + 1][i][nb], o0 + i * 32, lhi, g.Cm, pvld, pos0 + (size_t)ph * g.dW, (size_t)dHW,
+                          (g.fused_atomic && blockIdx.z) ? nullptr : g.res, g.mask_y, g.mask_act, g.dst, g.fused_atomic != 0);
+    } else {
+      const size_t pos = (size_t)gb_ * g.Cm * dHW + (size_t)(glt * g.oT + g.pT) * g.dH * g.dW + (size_t)gh * g.dW + gw;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        if (g.ksplit > 1)
+          epilogue_tile16(acc[0][i][nb], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, blockIdx.z ? nullptr : g.bias, P2I_ACT_NONE,
+                          blockIdx.z ? nullptr : g.res, g.mask_y, g.mask_act, g.dst, true);
+        else
+          epilogue_tile16(acc[0][i][nb], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, g.bias, g.act_epi, g.res, g.mask_y, g.mask_act, g.dst);
+    }
+  }
+}
+
 // Fewest workgroups for which a tile variant is used (256 CUs; below that the next smaller tile, or the f32 engine).  Read per call
 // (not cached) so that the parity tests can send small layers through these kernels (P2I_X6C_MIN_WG=1).
 static int x6c_min_wg() { const char* e = getenv("P2I_X6C_MIN_WG"); return e ? atoi(e) : 200; }
@@ -597,6 +926,20 @@ static void x6c_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
   }
   hipLaunchKernelGGL((patch_gemm_x6c_kernel<NW, TM, FUSED, TPS>), grid, dim3(64 * NW), lds, s, g);
 }
+template <int TM, int TPS, bool FUSED = false>
+static void x6p_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)patch_gemm_x6p_kernel<TM, TPS, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((patch_gemm_x6p_kernel<TM, TPS, FUSED>), grid, dim3(512), lds, s, g);
+}
+// Producer / consumer wave roles (patch_gemm_x6p_kernel): the default for every layer with more than one 16-channel chunk;
+// P2I_X6C_PC=0 keeps the symmetric kernels; read per call (A/B runs).  Measured at B = 8, symmetric -> producer / consumer
+// (gpurun_out/r03f/pc0.log, pc2.log): 64-channel level 75.4 -> 75.8 / 79.0 -> 73.9 us (fwd / dgrad), 128: 62.3 -> 57.4, 256: 64.3 ->
+// 56.3, 512: 75.8 -> 68.6, 3-D 128 -> 128: 86.0 -> 76.5; K = 16 (16 -> 64 forward): 36.8 -> 39.9, hence the exception.
+static int x6c_pc() { const char* e = getenv("P2I_X6C_PC"); return e ? atoi(e) : 1; }
 // taps per stage of the 32-channel tiles: 9 (whole chunk) unless P2I_X6C_TPS=3 (read per call: A/B runs)
 static int x6c_tps1() { const char* e = getenv("P2I_X6C_TPS"); return (e && atoi(e) == 3) ? 3 : 9; }
 static size_t x6c_lds_bytes(int csl, int tm, int tps) {
@@ -671,7 +1014,7 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
     if (hipMemsetAsync(g.dst, 0, sizeof(float) * (size_t)n_dst, s) != hipSuccess) return P2I_EINVAL;
     if (post_act != P2I_ACT_NONE) { post_res = g.res; g.res = nullptr; g.act_epi = P2I_ACT_NONE; }   // act(sum + bias) + res: second pass
   }
-  if (plan6) { plan6[0] = 32 * tv.TM; plan6[1] = 32 * tv.NW; plan6[2] = pk.ksplit; plan6[3] = 16; plan6[4] = tps; plan6[5] = 7; }
+  if (plan6) { plan6[0] = 32 * tv.TM; plan6[1] = 32 * tv.NW; plan6[2] = pk.ksplit; plan6[3] = (x6c_pc() && g.Ck >= 32) ? 4 : 8; plan6[4] = tps; plan6[5] = 7; }
   X6cGeom k{};
   k.src = g.src; k.dst = g.dst; k.wb = g.wb; k.bias = g.bias; k.res = g.res; k.mask_y = g.mask_y;
   k.wb_bytes = g.wb_bytes; k.act_epi = g.act_epi; k.mask_act = g.mask_act;
@@ -685,7 +1028,12 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   k.sdt0 = cs.dt[0]; k.swt0 = 0;
   k.sdt1 = ns > 1 ? cs.dt[9] : 0; k.swt1 = ns > 1 ? cs.tw[9] - cs.tw[0] : 0;
   k.sdt2 = ns > 2 ? cs.dt[18] : 0; k.swt2 = ns > 2 ? cs.tw[18] - cs.tw[0] : 0;
-  if (tv.TM == 2) x6c_launch<8, 2>(k, grid, lds, s);
+  const int pc = x6c_pc();
+  if (pc && g.Ck >= 32) {                                 // (a single 16-channel chunk is all prologue and epilogue: symmetric kernel)
+    if (tv.TM == 2) x6p_launch<2, 3>(k, grid, lds, s);
+    else if (tps == 9) x6p_launch<1, 9>(k, grid, lds, s);
+    else x6p_launch<1, 3>(k, grid, lds, s);
+  } else if (tv.TM == 2) x6c_launch<8, 2>(k, grid, lds, s);
   else if (tps == 9) x6c_launch<8, 1, false, 9>(k, grid, lds, s);
   else x6c_launch<8, 1>(k, grid, lds, s);
   if (post_act != P2I_ACT_NONE) {
@@ -773,8 +1121,9 @@ int run_patch_gemm_x6c_fused(PatchGeom g, const ClassSpec* css, int ncls, const 
   const dim3 grid((unsigned)(ceil_div((int)nimg, jb) * k.nth * k.ntw), (unsigned)ceil_div(g.Cm, 32), (unsigned)ksplit);
   const int tps = x6c_tps1();
   const size_t lds = x6c_lds_bytes(k.CSl, 1, tps);
-  if (plan6) { plan6[0] = 32; plan6[1] = 256; plan6[2] = ksplit; plan6[3] = 16; plan6[4] = tps; plan6[5] = 8; }
-  if (tps == 9) x6c_launch<8, 1, true, 9>(k, grid, lds, s);
+  if (plan6) { plan6[0] = 32; plan6[1] = 256; plan6[2] = ksplit; plan6[3] = (x6c_pc() && tps == 9 && g.Ck >= 32) ? 4 : 8; plan6[4] = tps; plan6[5] = 8; }
+  if (x6c_pc() && tps == 9 && g.Ck >= 32) x6p_launch<1, 9, true>(k, grid, lds, s);
+  else if (tps == 9) x6c_launch<8, 1, true, 9>(k, grid, lds, s);
   else x6c_launch<8, 1, true>(k, grid, lds, s);
   return launch_status();
 }

@@ -101,11 +101,16 @@ def _prof_end(e0, kind, spec, desc, stride1):
         _hip.load().p2i_conv_last_plan(plan)
         if plan[5] > 10:
             key = "patch_gemm_fused_kernel<%d, %d, %d, %d, %d> (strided dgrad, %d parity classes per workgroup)" % (plan[0], plan[1], plan[2], plan[3], plan[5] - 10, plan[5] - 10)
+        elif plan[5] == 7 and plan[3] == 4:        # producer / consumer wave roles
+            key = "patch_gemm_x6p_kernel<%d, %d, false> (%d x %d tile, %d taps per stage, producer / consumer waves, bf16-split x6)" % (
+                plan[0] // 32, plan[4], plan[0], plan[1], plan[4])
         elif plan[5] == 7:
             key = "patch_gemm_x6c_kernel<%d, %d, false, %d> (%d x %d tile, %d taps per stage, bf16-split x6)" % (
                 plan[1] // 32, plan[0] // 32, plan[4], plan[0], plan[1], plan[4])
         elif plan[5] == 3:
             key = "o1_fwd_kernel (single output channel, bandwidth-bound)"
+        elif plan[5] == 8 and plan[3] == 4:
+            key = "patch_gemm_x6p_kernel<1, %d, true> (strided dgrad, 4 parity classes per workgroup, producer / consumer waves, bf16-split x6)" % plan[4]
         elif plan[5] == 8:
             key = "patch_gemm_x6c_kernel<8, 1, true, %d> (strided dgrad, 4 parity classes per workgroup, bf16-split x6)" % plan[4]
         else:
