@@ -96,6 +96,69 @@ __device__ __forceinline__ void epilogue_tile16(const f32x16& acc, int o_base, i
   }
 }
 
+// epilogue_tile16 with 16-byte global accesses.  The 32x32 accumulator tile has one POSITION per lane and the 16 destination channels
+// in the registers, so the plain epilogue stores one dword per lane and channel: 16 store instructions of 2 x 128 B per tile (and 16
+// loads per residual / mask tensor).  At the end of the bf16-split kernels those instructions, not the bytes, bound the epilogue
+// (stamped: 17 k of 93 k cycles of a 64 x 256 tile workgroup).  Here the tile goes through a 32 x 36-float LDS image (wave-private,
+// any LDS is free after the main loop) and comes back with four consecutive positions of one channel per lane: 4 dwordx4 stores
+// (and 4 dwordx4 loads per epilogue tensor) per tile.  Requirements, checked by the caller: the wave's 32 positions are 8 aligned
+// groups of 4 consecutive destination elements (tile width >= 4 positions, destination row pitch and tile origin multiples of 4),
+// validity is per group (nW % 4 == 0).  pos4_off: element offset of THIS lane's group (lane & 7) inside a channel; pv4: group valid.
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void epilogue_tile16_v4(const f32x16& acc, float* __restrict__ tile_lds, int o_base, int lane, int Cm,
+                                                   size_t pos4_off, bool pv4, size_t chan_stride,
+                                                   const float* __restrict__ bias, int act_epi, const float* __restrict__ res,
+                                                   const float* __restrict__ mask_y, int mask_act, float* __restrict__ dst, bool atomic_out = false) {
+  constexpr int PITCH = 36;
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile_lds[((r & 3) + 8 * (r >> 2) + 4 * lhi) * PITCH + l31] = acc[r];
+  // (wave-private image: the hardware orders a wave's own LDS accesses; the compiler's lgkmcnt wait covers the read-after-write)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int p4 = (lane & 7) * 4;
+  int di[4];
+  bool ok[4];
+  f32x4e v[4], rv[4], mv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ch = k * 8 + (lane >> 3);                       // channel of this lane's k-th group
+    const int o = o_base + ch;
+    ok[k] = pv4 && o < Cm;
+    di[k] = ok[k] ? (int)((size_t)o * chan_stride + pos4_off) : 0;
+    v[k] = *reinterpret_cast<const f32x4e*>(tile_lds + ch * PITCH + p4);
+  }
+  if (res) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rv[k] = *reinterpret_cast<const f32x4e*>(res + di[k]);
+  }
+  if (mask_y) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mv[k] = *reinterpret_cast<const f32x4e*>(mask_y + di[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int o = o_base + k * 8 + (lane >> 3);
+    const float bv = bias ? bias[o < Cm ? o : 0] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = act_apply(v[k][e] + bv, act_epi);
+      if (res) x += rv[k][e];
+      if (mask_y) x = act_grad(x, mv[k][e], mask_act);
+      v[k][e] = x;
+    }
+    if (ok[k]) {
+      if (atomic_out) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dst + di[k] + e, v[k][e]);
+      } else {
+        *reinterpret_cast<f32x4e*>(dst + di[k]) = v[k];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();                            // the next tile of this wave reuses the image
+}
+
 // Epilogue of TWO accumulator tiles whose destinations interleave along w (input-parity classes (.., pW=0) and (.., pW=1) of a
 // stride-2 data gradient, destination row pitch even): element r of both tiles belongs to the same lane and to adjacent
 // addresses, so residual / mask are fetched and the result is stored as float2 -- full 128-B lines per 16 lanes instead of two

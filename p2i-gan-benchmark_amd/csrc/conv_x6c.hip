@@ -121,6 +121,7 @@ struct X6cGeom {
   int tap_w[9];
   int fused_atomic;     // FUSED kernels with split-K: the class pairs are ADDED to a zeroed destination
   int stagger;          // waves 4-7 (the SIMD partners of waves 0-3) run a stage's staging work AFTER its first taps instead of before
+  int vec4_epi;         // epilogue through LDS with 16-byte global accesses (epilogue_tile16_v4): host-checked alignment / extents
 };
 
 // FUSED (data gradient of a stride-(.,2,2) 3x3 convolution: conv_fused.hip on the bf16 matrix pipe): the nine taps of a chunk belong
@@ -137,18 +138,264 @@ template <int NW> struct X6cTile {
   static constexpr int NI = (2 * MAXCSL + 64 * NW - 1) / (64 * NW);
 };
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant); n > 63 cannot happen here
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant): a balanced tree of scalar compares, six
+// deep.  (A `switch` over the 61 cases compiled to a LINEAR chain of compare + branch: ~3 n scalar instructions per wait, two or
+// three waits per stage -- a third of a producer wave's instructions, tools: histogram of the loop in the .s.)  n >= 63: vmcnt(0).
 __device__ __forceinline__ void x6c_wait_vm(int n) {
-#define P2I_WC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    P2I_WC(0) P2I_WC(1) P2I_WC(2) P2I_WC(3) P2I_WC(4) P2I_WC(5) P2I_WC(6) P2I_WC(7) P2I_WC(8) P2I_WC(9) P2I_WC(10) P2I_WC(11) P2I_WC(12)
-    P2I_WC(13) P2I_WC(14) P2I_WC(15) P2I_WC(16) P2I_WC(17) P2I_WC(18) P2I_WC(19) P2I_WC(20) P2I_WC(21) P2I_WC(22) P2I_WC(23) P2I_WC(24)
-    P2I_WC(25) P2I_WC(26) P2I_WC(27) P2I_WC(28) P2I_WC(29) P2I_WC(30) P2I_WC(31) P2I_WC(32) P2I_WC(33) P2I_WC(34) P2I_WC(35) P2I_WC(36)
-    P2I_WC(37) P2I_WC(38) P2I_WC(39) P2I_WC(40) P2I_WC(41) P2I_WC(42) P2I_WC(43) P2I_WC(44) P2I_WC(45) P2I_WC(46) P2I_WC(47) P2I_WC(48)
-    P2I_WC(49) P2I_WC(50) P2I_WC(51) P2I_WC(52) P2I_WC(53) P2I_WC(54) P2I_WC(55) P2I_WC(56) P2I_WC(57) P2I_WC(58) P2I_WC(59) P2I_WC(60)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  if (n < 0 || n > 62) n = 0;
+  if (n < 32) {
+   if (n < 16) {
+    if (n < 8) {
+     if (n < 4) {
+      if (n < 2) {
+       if (n < 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+       }
+      } else {
+       if (n < 3) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+       }
+      }
+     } else {
+      if (n < 6) {
+       if (n < 5) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+       }
+      } else {
+       if (n < 7) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+       }
+      }
+     }
+    } else {
+     if (n < 12) {
+      if (n < 10) {
+       if (n < 9) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+       }
+      } else {
+       if (n < 11) {
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+       }
+      }
+     } else {
+      if (n < 14) {
+       if (n < 13) {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+       }
+      } else {
+       if (n < 15) {
+        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+       }
+      }
+     }
+    }
+   } else {
+    if (n < 24) {
+     if (n < 20) {
+      if (n < 18) {
+       if (n < 17) {
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+       }
+      } else {
+       if (n < 19) {
+        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+       }
+      }
+     } else {
+      if (n < 22) {
+       if (n < 21) {
+        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+       }
+      } else {
+       if (n < 23) {
+        asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
+       }
+      }
+     }
+    } else {
+     if (n < 28) {
+      if (n < 26) {
+       if (n < 25) {
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+       }
+      } else {
+       if (n < 27) {
+        asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+       }
+      }
+     } else {
+      if (n < 30) {
+       if (n < 29) {
+        asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(29)" ::: "memory");
+       }
+      } else {
+       if (n < 31) {
+        asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
+       }
+      }
+     }
+    }
+   }
+  } else {
+   if (n < 48) {
+    if (n < 40) {
+     if (n < 36) {
+      if (n < 34) {
+       if (n < 33) {
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
+       }
+      } else {
+       if (n < 35) {
+        asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(35)" ::: "memory");
+       }
+      }
+     } else {
+      if (n < 38) {
+       if (n < 37) {
+        asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(37)" ::: "memory");
+       }
+      } else {
+       if (n < 39) {
+        asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(39)" ::: "memory");
+       }
+      }
+     }
+    } else {
+     if (n < 44) {
+      if (n < 42) {
+       if (n < 41) {
+        asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(41)" ::: "memory");
+       }
+      } else {
+       if (n < 43) {
+        asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(43)" ::: "memory");
+       }
+      }
+     } else {
+      if (n < 46) {
+       if (n < 45) {
+        asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(45)" ::: "memory");
+       }
+      } else {
+       if (n < 47) {
+        asm volatile("s_waitcnt vmcnt(46)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(47)" ::: "memory");
+       }
+      }
+     }
+    }
+   } else {
+    if (n < 56) {
+     if (n < 52) {
+      if (n < 50) {
+       if (n < 49) {
+        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(49)" ::: "memory");
+       }
+      } else {
+       if (n < 51) {
+        asm volatile("s_waitcnt vmcnt(50)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(51)" ::: "memory");
+       }
+      }
+     } else {
+      if (n < 54) {
+       if (n < 53) {
+        asm volatile("s_waitcnt vmcnt(52)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(53)" ::: "memory");
+       }
+      } else {
+       if (n < 55) {
+        asm volatile("s_waitcnt vmcnt(54)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(55)" ::: "memory");
+       }
+      }
+     }
+    } else {
+     if (n < 60) {
+      if (n < 58) {
+       if (n < 57) {
+        asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(57)" ::: "memory");
+       }
+      } else {
+       if (n < 59) {
+        asm volatile("s_waitcnt vmcnt(58)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(59)" ::: "memory");
+       }
+      }
+     } else {
+      if (n < 62) {
+       if (n < 61) {
+        asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(61)" ::: "memory");
+       }
+      } else {
+       if (n < 63) {
+        asm volatile("s_waitcnt vmcnt(62)" ::: "memory");
+       } else {
+        asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+       }
+      }
+     }
+    }
+   }
   }
-#undef P2I_WC
 }
 
 // TPS = taps per pipeline stage (one hand-over barrier per stage): 3 = one kernel row, 9 = the whole 16-channel chunk.  A 32-channel
@@ -506,7 +753,7 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
 // the split pass and all weight DMAs.  A consumer's instruction stream never contains a vector-memory wait, a split pass or a DMA
 // issue; the producers' VALU / VMEM work runs on the same SIMDs beside the MFMAs and they park at the stage barrier when done.
 // Same numerics, same epilogue, same X6cGeom.
-template <int TM, int TPS, bool FUSED = false>
+template <int TM, int TPS, bool FUSED = false, bool EPI4 = false>
 __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
   constexpr int NSTG = 9 / TPS;
   constexpr int NCLS = FUSED ? 4 : 1;                     // FUSED: see X6C_CLS (strided data gradient, four parity classes)
@@ -553,6 +800,10 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
   }
   __syncthreads();                                                        // ptab visible
 
+#ifdef P2I_STAMP
+  unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, st_f = 0, st_t0, st_t1, st_l0 = 0, st_l1 = 0, st_entry;
+  X6C_NOW(st_entry);
+#endif
   if (wave >= NPW) {
     // =============================================================== producers
     const int ptid = tid - NPT, pw = wave - NPW;
@@ -655,7 +906,14 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
       x6c_wait_vm(n);
       __builtin_amdgcn_sched_barrier(0);
       split_patch(planes);
-      x6c_wait_vm(n - nwb(0));
+      if constexpr (TPS == 9) {
+        // whole-chunk stages: the patch of chunk c+1 is LOADED during stage c-1 and split at the top of stage c, so that a producer
+        // never waits for loads it has just issued (a stage would otherwise be as long as a memory round trip); chunk 1 starts here
+        if (nch > 1) load_patch(1);
+        x6c_wait_vm(n - nwb(0) + (nch > 1 ? NPL : 0));                      // weights of stage 0: younger are W(1) .. and the loads of chunk 1
+      } else {
+        x6c_wait_vm(n - nwb(0));
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // hand-over of stage 0
@@ -665,18 +923,39 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
 #pragma unroll
       for (int b = 0; b < NSTG; ++b, ++s) {
         const int sa = s + LEAD;
-        if (b == 0 && more_c) load_patch(c + 1);
-        if (sa < nst) issue_w(c + (b + LEAD) / NSTG, (b + LEAD) % NSTG, sa % RING);   // slot read last in stage s-1
-        if (b == NSTG - 1 && more_c) {
-          // patch loads went out at the top of stage s - (NSTG - 1); younger: the weight batches of the stages since then
-          int n = 0;
+        if constexpr (TPS == 9) {
+#ifdef P2I_STAMP
+          X6C_NOW(st_t0);
+          if (s == 0) st_l0 = st_t0;
+#endif
+          if (more_c) {
+            // loads of chunk c+1: issued in the previous stage in front of its weight batch W(s-1+LEAD) (stage 0: in the prologue, last)
+            x6c_wait_vm(s == 0 ? 0 : nwb(s - 1 + LEAD));
+            X6C_ACC(st_a, st_t0);                                         // wait for the patch loads
+            __builtin_amdgcn_sched_barrier(0);
+            split_patch(planes + ((c + 1) & 1) * PST);                   // buffer read last in chunk c-1
+            __builtin_amdgcn_sched_barrier(0);
+            X6C_ACC(st_b, st_t0);                                         // split pass
+            if (c + 2 < nch) load_patch(c + 2);                          // into the registers the split has just consumed
+            X6C_ACC(st_e, st_t0);                                         // patch load issue
+          }
+          if (sa < nst) issue_w(c + LEAD, 0, sa % RING);                 // slot read last in stage s-1
+          X6C_ACC(st_f, st_t0);                                           // weight DMA issue
+          // stage s+1 needs W(s+1), issued at the top of stage s-1 (LEAD = 2); issued after it: the loads of chunk c+2 and W(s+2)
+          x6c_wait_vm(nwb(s + 2) + ((more_c && c + 2 < nch) ? NPL : 0));
+          X6C_ACC(st_c, st_t0);                                           // wait for the weights of the next stage
+        } else {
+          if (b == 0 && more_c) load_patch(c + 1);
+          if (sa < nst) issue_w(c + (b + LEAD) / NSTG, (b + LEAD) % NSTG, sa % RING);   // slot read last in stage s-1
+          if (b == NSTG - 1 && more_c) {
+            // patch loads went out at the top of stage s - (NSTG - 1); younger: the weight batches of the stages since then
+            int n = 0;
 #pragma unroll
-          for (int j = 0; j < NSTG; ++j) n += nwb(sa - j);
-          x6c_wait_vm(n);
-          __builtin_amdgcn_sched_barrier(0);
-          split_patch(planes + ((c + 1) & 1) * PST);                     // buffer read last in chunk c-1
-        }
-        {
+            for (int j = 0; j < NSTG; ++j) n += nwb(sa - j);
+            x6c_wait_vm(n);
+            __builtin_amdgcn_sched_barrier(0);
+            split_patch(planes + ((c + 1) & 1) * PST);                   // buffer read last in chunk c-1
+          }
           // stage s+1 needs W(s+1), issued at the top of stage s+1-LEAD.  Issued AFTER it (vmcnt counts in issue order, done or not):
           // W(s+2) .. W(s+LEAD) and the patch loads at the tops of the stages s+2-LEAD .. s that start a chunk with a successor
           int n = 0;
@@ -690,7 +969,14 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
           x6c_wait_vm(n);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // plane writes done
+#ifdef P2I_STAMP
+        X6C_NOW(st_t1);
+#endif
         __builtin_amdgcn_s_barrier();                                     // hand-over of stage s+1
+#ifdef P2I_STAMP
+        X6C_ACC(st_d, st_t1);                                             // parked at the stage barrier
+        st_l1 = st_t1;
+#endif
       }
     }
   }
@@ -742,6 +1028,7 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
           acc[cl][i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, A[buf][i][PA[q]]), __builtin_bit_cast(bf16x8c, Bv[buf][nb][PB[q]]),
                                                                    acc[cl][i][nb], 0, 0, 0);
   };
+  // (reads in consumption order, two per MFMA gap at the front of the tap: measured 2-4 % slower, gpurun_out/r03h/pc2.log)
   auto ilv = [&]() {
     constexpr int NR = 3 * TM + 6, NM = 12 * TM;
 #pragma unroll
@@ -769,8 +1056,17 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
           ilv();
           __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef P2I_STAMP
+        X6C_NOW(st_t0);
+        if (s == 0) st_l0 = st_t0;
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // own operand reads of this stage have returned
+        X6C_ACC(st_a, st_t0);
         __builtin_amdgcn_s_barrier();                                     // stage s+1 handed over
+#ifdef P2I_STAMP
+        X6C_ACC(st_d, st_t0);                                             // parked at the stage barrier
+        st_l1 = st_t0;
+#endif
         if (s + 1 < nst) load_tap(wlane + ((s + 1) % RING) * WST, b == NSTG - 1 ? pbn : pb, b == NSTG - 1 ? 0 : TPS * b + TPS, 0);
         mfma_tap(2, TPS * b + TPS - 1);
         ilv();
@@ -814,6 +1110,22 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
         for (int i = 0; i < TM; ++i)
           epilogue_pair16(acc[2 * ph][i][nb], acc[2 * ph + 1][i][nb], o0 + i * 32, lhi, g.Cm, pvld, pos0 + (size_t)ph * g.dW, (size_t)dHW,
                           (g.fused_atomic && blockIdx.z) ? nullptr : g.res, g.mask_y, g.mask_act, g.dst, g.fused_atomic != 0);
+    } else if constexpr (EPI4) {
+      // 16-byte accesses: this lane's group = positions 4 (lane & 7) .. + 3 of the block (one channel per lane and pass)
+      const int pg = cw * 64 + nb * 32 + 4 * (lane & 7);
+      const int qw = pg & JWm, qh = (pg >> g.ljw) & JHm, qb = pg >> (g.ljw + g.ljh);
+      const int hw = j0w + qw, hh = j0h + qh, hn = j0b + qb;
+      const bool pv4 = hn < nimg && hh < g.nH && hw < g.nW;
+      const int hb = hn / g.nT, hlt = hn - hb * g.nT;
+      const size_t pos4 = (size_t)hb * g.Cm * dHW + (size_t)(hlt * g.oT + g.pT) * g.dH * g.dW + (size_t)hh * g.dW + hw;
+      float* tl = xch + 4 * NCLS * TM * 16 * 64 + wave * (32 * 36);      // wave-private 32 x 36 image behind the exchange area
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        if (g.ksplit > 1)
+          epilogue_tile16_v4(acc[0][i][nb], tl, o0 + i * 32, lane, g.Cm, pos4, pv4, (size_t)dHW, blockIdx.z ? nullptr : g.bias, P2I_ACT_NONE,
+                             blockIdx.z ? nullptr : g.res, g.mask_y, g.mask_act, g.dst, true);
+        else
+          epilogue_tile16_v4(acc[0][i][nb], tl, o0 + i * 32, lane, g.Cm, pos4, pv4, (size_t)dHW, g.bias, g.act_epi, g.res, g.mask_y, g.mask_act, g.dst);
     } else {
       const size_t pos = (size_t)gb_ * g.Cm * dHW + (size_t)(glt * g.oT + g.pT) * g.dH * g.dW + (size_t)gh * g.dW + gw;
 #pragma unroll
@@ -825,6 +1137,14 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
           epilogue_tile16(acc[0][i][nb], o0 + i * 32, lhi, g.Cm, pvld, pos, (size_t)dHW, g.bias, g.act_epi, g.res, g.mask_y, g.mask_act, g.dst);
     }
   }
+#ifdef P2I_STAMP
+  if (p2i_stamp_buf && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long st_end; X6C_NOW(st_end);
+    unsigned long long* o = p2i_stamp_buf + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8 + wave) * 8;
+    o[0] = st_a; o[1] = st_d; o[2] = st_b; o[3] = st_c; o[4] = st_l1 - st_l0; o[5] = st_l0 - st_entry; o[6] = st_e; o[7] = st_end - st_l1;
+  }
+#endif
 }
 
 // Fewest workgroups for which a tile variant is used (256 CUs; below that the next smaller tile, or the f32 engine).  Read per call
@@ -926,14 +1246,14 @@ static void x6c_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
   }
   hipLaunchKernelGGL((patch_gemm_x6c_kernel<NW, TM, FUSED, TPS>), grid, dim3(64 * NW), lds, s, g);
 }
-template <int TM, int TPS, bool FUSED = false>
+template <int TM, int TPS, bool FUSED = false, bool EPI4 = false>
 static void x6p_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)patch_gemm_x6p_kernel<TM, TPS, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((patch_gemm_x6p_kernel<TM, TPS, FUSED>), grid, dim3(512), lds, s, g);
+  hipLaunchKernelGGL((patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4>), grid, dim3(512), lds, s, g);
 }
 // Producer / consumer wave roles (patch_gemm_x6p_kernel): the default for every layer with more than one 16-channel chunk;
 // P2I_X6C_PC=0 keeps the symmetric kernels; read per call (A/B runs).  Measured at B = 8, symmetric -> producer / consumer
@@ -1025,12 +1345,20 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   for (int i = 0; i < 9; ++i) { k.tap_off[i] = g.tap_off[i]; k.tap_w[i] = g.tap_w[i]; }
   k.sT = g.sT; k.nT = g.nT; k.mT = g.mT; k.oT = g.oT; k.pT = g.pT; k.ns = ns;
   k.stagger = x6c_stagger();
+  {
+    static const int v4_on = getenv("P2I_X6C_EPI4") ? atoi(getenv("P2I_X6C_EPI4")) : 1;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    // 64-channel tiles only (32-channel tiles: 57.9 vs 58.3 us, no gain) and never with split-K (its atomic adds want the plain
+    // epilogue's 32 contiguous dwords per instruction: 92 vs 69 us on the 512-channel level)
+    k.vec4_epi = v4_on && tv.TM == 2 && pk.ksplit == 1 && jw >= 4 && (cs.nW & 3) == 0 && (g.dW & 3) == 0 && al16(g.dst) && al16(g.res) && al16(g.mask_y) &&
+                 (32 * 36 * 8 + 4 * tv.TM * 16 * 64) * 4 <= (int)lds - 4 * ((g.CSl + 3) & ~3);
+  }
   k.sdt0 = cs.dt[0]; k.swt0 = 0;
   k.sdt1 = ns > 1 ? cs.dt[9] : 0; k.swt1 = ns > 1 ? cs.tw[9] - cs.tw[0] : 0;
   k.sdt2 = ns > 2 ? cs.dt[18] : 0; k.swt2 = ns > 2 ? cs.tw[18] - cs.tw[0] : 0;
   const int pc = x6c_pc();
   if (pc && g.Ck >= 32) {                                 // (a single 16-channel chunk is all prologue and epilogue: symmetric kernel)
-    if (tv.TM == 2) x6p_launch<2, 3>(k, grid, lds, s);
+    if (tv.TM == 2) { if (k.vec4_epi) x6p_launch<2, 3, false, true>(k, grid, lds, s); else x6p_launch<2, 3>(k, grid, lds, s); }
     else if (tps == 9) x6p_launch<1, 9>(k, grid, lds, s);
     else x6p_launch<1, 3>(k, grid, lds, s);
   } else if (tv.TM == 2) x6c_launch<8, 2>(k, grid, lds, s);
