@@ -753,13 +753,16 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
 // the split pass and all weight DMAs.  A consumer's instruction stream never contains a vector-memory wait, a split pass or a DMA
 // issue; the producers' VALU / VMEM work runs on the same SIMDs beside the MFMAs and they park at the stage barrier when done.
 // Same numerics, same epilogue, same X6cGeom.
-template <int TM, int TPS, bool FUSED = false, bool EPI4 = false>
-__global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
+// NPW = producer waves: 4 (one per SIMD beside its consumer) or 8 (two per SIMD: the 32-channel tiles' producers are otherwise as busy
+// as their consumers -- stamped: split pass 33 %, load issue 23 %, DMA issue 20 % of their loop, consumers 16 % at the stage barrier;
+// twelve waves leave 170 VGPRs per wave, which only the non-fused 32-channel kernel fits)
+template <int TM, int TPS, bool FUSED = false, bool EPI4 = false, int NPW = 4>
+__global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6cGeom g) {
   constexpr int NSTG = 9 / TPS;
   constexpr int NCLS = FUSED ? 4 : 1;                     // FUSED: see X6C_CLS (strided data gradient, four parity classes)
   static_assert(TPS == 3 || TPS == 9, "taps per stage");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int MB = 32 * TM, NTHR = 512, NPT = 256, NPW = 4;
+  constexpr int MB = 32 * TM, NCW = 4, NTHR = 64 * (NCW + NPW), NPT = 64 * NPW;
   constexpr int NI = (2 * X6cTile<8>::MAXCSL + NPT - 1) / NPT;            // patch items per producer thread: 3
   constexpr int RING = TPS == 9 ? 3 : (TM == 2 ? 4 : 6), LEAD = RING - 1;
   constexpr int WST = 6 * TPS * MB, NWI = WST / 64;
@@ -804,9 +807,9 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
   unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, st_f = 0, st_t0, st_t1, st_l0 = 0, st_l1 = 0, st_entry;
   X6C_NOW(st_entry);
 #endif
-  if (wave >= NPW) {
+  if (wave >= NCW) {
     // =============================================================== producers
-    const int ptid = tid - NPT, pw = wave - NPW;
+    const int ptid = tid - 64 * NCW, pw = wave - NCW;
     const v4i32 rs_w = make_rsrc(g.wb, g.wb_bytes);
     const unsigned wbuf_la = lds_base(smem) + 4u * ptab_sz;
     const int wl_m = TM == 2 ? lane : l31, wl_kg = TM == 2 ? 0 : lhi;
@@ -892,13 +895,11 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
     };
     const int nw_mine = (NWI / NPW) + (pw < NWI % NPW ? 1 : 0);
     constexpr int NPL = 8 * NI;
-    auto nwb = [&](int st) { return st < nst ? nw_mine : 0; };
-    // vector-memory operations of a producer wave, in issue order: prologue [P(0)] [W(0)] .. [W(LEAD-1)]; per stage s:
+    // (the weights of the first LEAD stages are DMA'd by the CONSUMER waves, which have nothing else to do during the prologue)
+    auto nwb = [&](int st) { return (st >= LEAD && st < nst) ? nw_mine : 0; };
+    // vector-memory operations of a producer wave, in issue order: prologue [P(0)]; per stage s:
     // [P(chunk+1) if the stage starts a chunk that has a successor] [W(s+LEAD)]
     load_patch(0);
-#pragma unroll
-    for (int st = 0; st < LEAD; ++st)
-      if (st < nst) issue_w(st / NSTG, st % NSTG, st % RING);
     {
       int n = 0;
 #pragma unroll
@@ -982,8 +983,8 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
   }
 
   // ================================================================= consumers (producers only set up the epilogue geometry here)
-  const bool producer = wave >= NPW;
-  const int cw = wave & (NPW - 1);                                       // positions [64 cw, 64 cw + 64); producer w helps consumer w - 4
+  const bool producer = wave >= NCW;
+  const int cw = wave & (NCW - 1);                                       // positions [64 cw, 64 cw + 64); producer w helps consumer w - 4
   int lane_base[2], pjw_[2], pjh_[2], pjb_[2];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
@@ -1039,6 +1040,28 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
   };
   const u32x4c* wlane = wbuf + lhi * MB + l31;
   if (!producer) {
+    {
+      // prologue: the weights of stages 0 .. LEAD-1 (the producers are busy with the first patch)
+      const v4i32 rs_w = make_rsrc(g.wb, g.wb_bytes);
+      const unsigned wbuf_la = lds_base(smem) + 4u * ptab_sz;
+      const int wl_m = TM == 2 ? lane : l31, wl_kg = TM == 2 ? 0 : lhi;
+      const int wvoff = (o0 + wl_m < g.CmPad) ? (wl_kg * g.CmPad + wl_m) * 16 : -16;
+      const int w_cstep = 2 * g.CmPad * 16, w_tstep = KCt * g.CmPad * 16;
+#pragma unroll
+      for (int st = 0; st < LEAD; ++st) {
+        if (st >= nst) break;
+        const int cg = c0 + st / NSTG, b = st % NSTG;
+        const int j = cg >= 2 * cps ? 2 : (cg >= cps ? 1 : 0);
+        const int soff = (cg - j * cps) * w_cstep + (j == 2 ? g.swt2 : (j == 1 ? g.swt1 : g.swt0)) * w_tstep;
+        for (int u = cw; u < NWI; u += NCW) {
+          const int pt = TM == 2 ? u >> 1 : u, kg = TM == 2 ? u & 1 : 0;
+          const int p = pt / TPS, tl = pt % TPS;
+          const int so = (((p * g.ntaps_w + g.tap_w[TPS * b + tl]) * KCt + kg) * g.CmPad + o0) * 16 + soff;
+          dma_b128(rs_w, wbuf_la + 16u * (unsigned)(u * 64 + (st % RING) * WST), wvoff, so);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                                         // stage 0 handed over by the producers
     load_tap(wlane, planes, 0, 0);
     int s = 0;
@@ -1087,6 +1110,7 @@ __global__ __launch_bounds__(512) void patch_gemm_x6p_kernel(const X6cGeom g) {
         for (int r = 0; r < 16; ++r) xch[(((cw * NCLS + q) * TM + i) * 16 + r) * 64 + lane] = acc[q][i][1][r];
   }
   __syncthreads();
+  if (wave >= 2 * NCW) return;                                            // (a second producer wave per SIMD has no share in the epilogue)
   if (producer) {
 #pragma unroll
     for (int q = 0; q < NCLS; ++q)
@@ -1246,15 +1270,17 @@ static void x6c_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
   }
   hipLaunchKernelGGL((patch_gemm_x6c_kernel<NW, TM, FUSED, TPS>), grid, dim3(64 * NW), lds, s, g);
 }
-template <int TM, int TPS, bool FUSED = false, bool EPI4 = false>
+template <int TM, int TPS, bool FUSED = false, bool EPI4 = false, int NPW = 4>
 static void x6p_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4>), grid, dim3(512), lds, s, g);
+  hipLaunchKernelGGL((patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW>), grid, dim3(64 * (4 + NPW)), lds, s, g);
 }
+// P2I_X6P_NPW=4: one producer wave per SIMD for the 32-channel tiles too (default 8); read per call (A/B runs)
+static int x6p_npw() { const char* e = getenv("P2I_X6P_NPW"); return (e && atoi(e) == 4) ? 4 : 8; }
 // Producer / consumer wave roles (patch_gemm_x6p_kernel): the default for every layer with more than one 16-channel chunk;
 // P2I_X6C_PC=0 keeps the symmetric kernels; read per call (A/B runs).  Measured at B = 8, symmetric -> producer / consumer
 // (gpurun_out/r03f/pc0.log, pc2.log): 64-channel level 75.4 -> 75.8 / 79.0 -> 73.9 us (fwd / dgrad), 128: 62.3 -> 57.4, 256: 64.3 ->
@@ -1359,7 +1385,7 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   const int pc = x6c_pc();
   if (pc && g.Ck >= 32) {                                 // (a single 16-channel chunk is all prologue and epilogue: symmetric kernel)
     if (tv.TM == 2) { if (k.vec4_epi) x6p_launch<2, 3, false, true>(k, grid, lds, s); else x6p_launch<2, 3>(k, grid, lds, s); }
-    else if (tps == 9) x6p_launch<1, 9>(k, grid, lds, s);
+    else if (tps == 9) { if (x6p_npw() == 8) x6p_launch<1, 9, false, false, 8>(k, grid, lds, s); else x6p_launch<1, 9>(k, grid, lds, s); }
     else x6p_launch<1, 3>(k, grid, lds, s);
   } else if (tv.TM == 2) x6c_launch<8, 2>(k, grid, lds, s);
   else if (tps == 9) x6c_launch<8, 1, false, 9>(k, grid, lds, s);
