@@ -431,7 +431,11 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             tj = json.load(open(pmc))
-            traffic = tj.get("kernels", tj).get(dom_name)
+            kt = tj.get("kernels", tj)
+            traffic = kt.get(dom_name)
+            if traffic is None:            # rocprofv3 prints trailing template arguments the plan does not carry (epilogue form, producer waves)
+                cand = [v for k_, v in kt.items() if k_.startswith(dom_name.rstrip(">"))]
+                traffic = cand[0] if len(cand) == 1 else None
             traffic_src = tj.get("source")
         note = "instrumented pass: every launch on one stream (P2I_SIDE_WGRAD=0), so a launch's duration is the kernel's own"
         if dom.startswith(("wgrad_dma_kernel", "wgrad_x6_kernel")) and ops.WGRAD_SLICES:
