@@ -1174,6 +1174,9 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
 // Fewest workgroups for which a tile variant is used (256 CUs; below that the next smaller tile, or the f32 engine).  Read per call
 // (not cached) so that the parity tests can send small layers through these kernels (P2I_X6C_MIN_WG=1).
 static int x6c_min_wg() { const char* e = getenv("P2I_X6C_MIN_WG"); return e ? atoi(e) : 200; }
+// the fused strided data gradient is taken from 128 workgroups on (half the chip, one round: the 128 -> 256 stride-2 layer at B = 8);
+// its f32 alternative is no faster per workgroup.  P2I_X6C_MIN_WG overrides both thresholds (tests).
+static int x6c_fused_min_wg() { const char* e = getenv("P2I_X6C_MIN_WG"); return e ? atoi(e) : 128; }
 // P2I_X6C_TILE=<NW><TM> (82, 81) forces one variant (tests, tuning)
 static int x6c_forced() { const char* e = getenv("P2I_X6C_TILE"); return e ? atoi(e) : 0; }
 
@@ -1227,7 +1230,7 @@ bool x6c_would_take(const p2i_conv_desc* d, bool dgrad, int act_epi) {
     if (jt != 1 || jb * (jh + 1) * (jw + 1) > X6cTile<8>::MAXCSL) return false;
     const long long tiles = (long long)ceil_div(nimg, jb) * ceil_div(nH, jh) * ceil_div(nW, jw) * ceil_div(d->Cin, 32);
     const bool can_split = x6c_fused_ksplit() && (((d->kt * (d->Cout >> 4)) & 1) == 0);
-    return tiles >= x6c_min_wg() || (can_split && 2 * tiles >= x6c_min_wg());
+    return tiles >= x6c_fused_min_wg() || (can_split && 2 * tiles >= x6c_fused_min_wg());
   }
   if (!on || d->kh != 3 || d->kw != 3 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1) return false;
   const bool flat = d->kt == 1 && d->st == 1 && d->pt == 0;           // 2-D layer (or frames convolved independently)
@@ -1443,7 +1446,7 @@ int run_patch_gemm_x6c_fused(PatchGeom g, const ClassSpec* css, int ncls, const 
   // split-K for layers with too few tiles: measured SLOWER than the f32 fused kernel on the one layer of the step it would take
   // (128 -> 256 stride 2 at B = 8: 90.6 vs 72 us, the float2 pairs become two atomics each), so it is off unless asked for
   const bool can_split = x6c_fused_ksplit() && !alias && ((ns * cps) & 1) == 0 && c0.oT == 1 && c0.pT == 0 && c0.nT == g.dT;
-  const int min_wg = x6c_min_wg();
+  const int min_wg = x6c_fused_min_wg();
   int ksplit = 1;
   if (tiles < min_wg) {
     if (can_split && 2 * tiles >= min_wg) ksplit = 2;

@@ -134,7 +134,7 @@ def _x6_scratch(numel: int, device):
     kernel and its consumer are stream-ordered, so the next call may overwrite it)."""
     if CONV_ENGINE not in ("auto", "x6"):
         return None
-    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    key = (device.index, _stream())
     buf = _X6_SCRATCH.get(key)
     if buf is None or buf.numel() < numel:
         buf = torch.empty(max(numel, 1 << 22), device=device, dtype=torch.int16)
@@ -224,7 +224,7 @@ _WGRAD_WS = {}
 def _wgrad_scratch(device):
     if not WGRAD_SLICES:
         return None
-    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    key = (device.index, _stream())
     buf = _WGRAD_WS.get(key)
     if buf is None:
         buf = torch.empty(256 * 9 * 64 * 64 + 1024, device=device, dtype=torch.float32)

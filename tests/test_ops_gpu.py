@@ -61,16 +61,20 @@ def _act_cpu(y, act):
     return {"none": lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.2), "tanh": torch.tanh}[act](y)
 
 
-@pytest.fixture(params=["f32", "x6c", "x6c81"])
+@pytest.fixture(params=["f32", "x6c", "x6c81", "x6c_sym"])
 def engine(request, ops, monkeypatch):
-    """Both convolution engines are held to the same oracle: the f32-MFMA kernels and the bf16-split kernels (conv_x6c.hip).  The
-    latter only take layers with >= 200 workgroups by default; P2I_X6C_MIN_WG=1 (read per call) sends the small test layers
-    they cover through them too, and P2I_X6C_TILE=<waves><channel tiles> pins one tile variant (default: 82 = 64 x 256 where it fills the chip, else 81 = 32 x 256)."""
+    """Both convolution engines are held to the same oracle: the f32-MFMA kernels and the bf16-split kernels (conv_x6c.hip: producer /
+    consumer kernels by default, "x6c_sym" = the symmetric ones).  The latter only take layers with >= 200 workgroups by default;
+    P2I_X6C_MIN_WG=1 (read per call) sends the small test layers they cover through them too, and P2I_X6C_TILE=<waves><channel tiles>
+    pins one tile variant (default: 82 = 64 x 256 where it fills the chip, else 81 = 32 x 256)."""
     old = ops.CONV_ENGINE
     ops.CONV_ENGINE = "f32" if request.param == "f32" else "auto"
     if request.param != "f32":
         monkeypatch.setenv("P2I_X6C_MIN_WG", "1")
-        if request.param != "x6c":
+        if request.param == "x6c_sym":         # the symmetric kernels (all eight waves stage and multiply) with kernel-row stages: the
+            monkeypatch.setenv("P2I_X6C_PC", "0")      # round-2 schedule, kept as the A/B baseline and for K = 16 layers
+            monkeypatch.setenv("P2I_X6C_TPS", "3")
+        elif request.param != "x6c":
             monkeypatch.setenv("P2I_X6C_TILE", request.param[3:])
     yield request.param
     ops.CONV_ENGINE = old
