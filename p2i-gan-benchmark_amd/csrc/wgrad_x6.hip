@@ -307,6 +307,197 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
   else emit([](float* o, float v) { atomicAdd(o, v); });
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// "wgrad_x6p": the same LDS images, transposed operand reads, slices and numerics as wgrad_x6_kernel with the eight waves SPECIALISED
+// (the scheme that took the convolution kernels from 63 % to 86 % of their MFMA-bound loop time, conv_x6c.hip "x6p"): waves 0-3 are
+// CONSUMERS -- one per SIMD, channel quadrant (kh, mh), ALL nine taps (nine 32x32 accumulators), nothing but transposed reads and
+// MFMAs: 216 MFMAs per 64-pixel tile -- and waves 4-7 are PRODUCERS: they load tile i+2 into registers (hardware zero for the halo),
+// split and write tile i+1 into the other buffer, and sum the bias gradient on the way.  One barrier per tile.
+__global__ __launch_bounds__(512) void wgrad_x6p_kernel(const Wx6Geom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int HW = g.H * g.W;
+  const int cb = blockIdx.y, ob = blockIdx.z % g.nco, ta = blockIdx.z / g.nco;
+  const int dta = ta == 2 ? g.dt[2] : (ta == 1 ? g.dt[1] : g.dt[0]);
+  const int xcs = g.sT * HW, ycs = g.nT * HW;
+  const int nmine = blockIdx.x < g.ntiles ? (g.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;   // tiles of this workgroup
+
+  if (wave >= 4) {
+    // =============================================================== producers
+    const int p = tid - 256;
+    constexpr int NX = (8 * WX_XPX + 255) / 256;       // x items (patch pixel, 8-channel chunk) per thread: 4
+    constexpr int NY = (8 * WX_YPX) / 256;             // dy items per thread: 2
+    int x_rel[NX], x_dst[NX], x_qr[NX], x_qc[NX];
+    bool x_in[NX];
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int e = p + 256 * it;
+      x_in[it] = e < 8 * WX_XPX;
+      const int chunk = x_in[it] ? e / WX_XPX : 0, q = x_in[it] ? e - chunk * WX_XPX : 0;
+      const int qr = q / WX_EW, qc = q - qr * WX_EW;
+      x_qr[it] = x_in[it] ? qr - 1 : -(1 << 20);
+      x_qc[it] = qc - 1;
+      x_rel[it] = (cb * 64 + chunk * 8) * xcs + (qr - 1) * g.W + (qc - 1);
+      x_dst[it] = q * WX_ROW + chunk * 16;
+    }
+    int y_rel[NY], y_dst[NY];
+#pragma unroll
+    for (int it = 0; it < NY; ++it) {
+      const int e = p + 256 * it;                      // = chunk * 64 + pixel: a wave holds the 64 pixels of one 8-channel chunk
+      const int chunk = e >> 6, q = e & 63;
+      y_rel[it] = (ob * 64 + chunk * 8) * ycs + (q >> 4) * g.W + (q & 15);
+      y_dst[it] = WX_YOFF + q * WX_ROW + chunk * 16;
+    }
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, (int)g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dy), 0, (int)g.dy_bytes, 0x00020000);
+    const int xchan_bytes = 4 * xcs, ychan_bytes = 4 * ycs;
+    float xv[NX][8], yv[NY][8];
+    auto load_tile = [&](int t) {
+      const int tw = t % g.ntw, r0 = t / g.ntw;
+      const int th = r0 % g.nth, img = r0 / g.nth;
+      const int b = img / g.nT, to = img - b * g.nT;
+      const int ti = to * g.mT + dta;
+      const bool tok = (unsigned)ti < (unsigned)g.sT;
+      const int h0 = th * WX_TH, w0 = tw * WX_TW;
+      const int xorg = (b * g.Cx * g.sT + ti) * HW + h0 * g.W + w0, yorg = (b * g.Co * g.nT + to) * HW + h0 * g.W + w0;
+#pragma unroll
+      for (int it = 0; it < NX; ++it) {
+        const int h = h0 + x_qr[it], w = w0 + x_qc[it];
+        const bool ok = tok && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+        const unsigned so = ok ? 4u * (unsigned)(xorg + x_rel[it]) : 0xFFFFFF00u;       // out of range: the hardware returns 0
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, so, j * xchan_bytes, 0));
+      }
+#pragma unroll
+      for (int it = 0; it < NY; ++it) {
+        const unsigned so = 4u * (unsigned)(yorg + y_rel[it]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) yv[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_y, so, j * ychan_bytes, 0));
+      }
+    };
+    const bool do_bias = g.dbias != nullptr && cb == 0 && ta == 0;
+    float bsum[NY][8];
+#pragma unroll
+    for (int it = 0; it < NY; ++it)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum[it][j] = 0.f;
+    auto split3 = [&](float (&v)[8], unsigned char* dst, int plane_bytes) {      // three planes of one item, exact truncation split
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        u32x4w w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = wx_pack(v[2 * j], v[2 * j + 1]);
+        *reinterpret_cast<u32x4w*>(dst + pl * plane_bytes) = w;
+        if (pl < 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] - wx_trunc(v[j]);
+        }
+      }
+    };
+    auto write_tile = [&](unsigned char* buf) {
+      if (do_bias) {
+#pragma unroll
+        for (int it = 0; it < NY; ++it)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[it][j] += yv[it][j];
+      }
+#pragma unroll
+      for (int it = 0; it < NX; ++it)
+        if (x_in[it]) split3(xv[it], buf + x_dst[it], WX_XPLANE);
+#pragma unroll
+      for (int it = 0; it < NY; ++it) split3(yv[it], buf + y_dst[it], WX_YPLANE);
+    };
+    int t = blockIdx.x;
+    if (nmine > 0) { load_tile(t); write_tile(wsm); }
+    if (nmine > 1) load_tile(t + gridDim.x);
+    __syncthreads();                                                     // tile 0 handed over
+    for (int i = 0; i < nmine; ++i) {
+      // consumers read buffer i & 1; tile i+1 (in registers since the previous trip) goes into the other one, tile i+2 into registers
+      if (i + 1 < nmine) write_tile(wsm + ((i + 1) & 1) * WX_BUF);
+      if (i + 2 < nmine) load_tile(t + (i + 2) * gridDim.x);
+      __syncthreads();
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int it = 0; it < NY; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float sj = wave_sum(bsum[it][j]);
+          if (lane == 0) atomicAdd(g.dbias + ob * 64 + (((p + 256 * it) >> 6)) * 8 + j, sj);
+        }
+    }
+    return;
+  }
+
+  // ================================================================= consumers
+  const int kh = wave >> 1, mh = wave & 1;                                // x-channel half, dy-channel half of the 64 x 64 block
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1, lhi = lane >> 5, l31 = lane & 31;
+  f32x16 acc[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+  const int a_lane = (8 * lhi + (i16 >> 2)) * WX_ROW + (32 * kh + 16 * g16 + 4 * (i16 & 3)) * 2;
+  const int b_lane = WX_YOFF + (8 * lhi + (i16 >> 2)) * WX_ROW + (32 * mh + 16 * g16 + 4 * (i16 & 3)) * 2;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};            // small terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  constexpr int NSTEP = 36;                            // (tile row ks, tap): 4 x 9
+  __syncthreads();                                                       // tile 0 handed over
+  for (int i = 0; i < nmine; ++i) {
+    const unsigned char* buf = wsm + (i & 1) * WX_BUF;
+    bf16x8w Av[3][3], Bv[2][3];
+    auto load_a = [&](int set, int step) {
+      const int ks = step / 9, tap = step % 9;
+      const unsigned char* q = buf + a_lane + (ks * WX_EW + (tap / 3) * WX_EW + tap % 3) * WX_ROW;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) Av[set][pl] = wx_read_tr(q, pl * WX_XPLANE);
+    };
+    auto load_b = [&](int set, int ks) {
+      const unsigned char* q = buf + b_lane + ks * WX_TW * WX_ROW;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) Bv[set][pl] = wx_read_tr(q, pl * WX_YPLANE);
+    };
+    load_b(0, 0);
+    load_a(0, 0);
+    load_a(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      const int ks = st / 9, tap = st % 9;
+      const bool pre_a = st + 2 < NSTEP;
+      const bool pre_b = tap == 0 && ks + 1 < WX_TH;                       // first tap of a tile row: fetch the next row's dy
+      if (pre_a) load_a((st + 2) % 3, st + 2);
+      if (pre_b) load_b((ks + 1) & 1, ks + 1);
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Av[st % 3][PA[q]], Bv[ks & 1][PB[q]], acc[tap], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (pre_a && pre_b) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        else if (pre_a || pre_b) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  // ---- store / accumulate the nine [c][o] tiles of this quadrant
+  const size_t tap_stride = (size_t)g.Cx * g.CoPad;
+  float* dst = (g.partial ? g.partial + (size_t)blockIdx.x * g.pstride : g.dwp) + (size_t)ta * 9 * tap_stride +
+               ((size_t)cb * 64 + 32 * kh + 4 * lhi) * g.CoPad + ob * 64 + 32 * mh + l31;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+    float* dt = dst + tp * tap_stride;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float* o = dt + ((j & 3) + 8 * (j >> 2)) * g.CoPad;
+      if (g.partial) *o = acc[tp][j];
+      else atomicAdd(o, acc[tp][j]);
+    }
+  }
+}
+
 // 0 = launched (plan filled), 1 = not a case of this kernel (caller continues with the f32 kernels)
 int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp, float* dbias, float* ws, long long ws_floats,
                  int* ns_out, long long* slice_out, hipStream_t s) {
@@ -338,9 +529,16 @@ int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float*
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)wgrad_x6p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_x6_kernel, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
+  // P2I_WGRAD_X6_PC=1: the producer / consumer variant.  Measured SLOWER than the symmetric kernel at B = 8 (gpurun_out/r03n: 64-channel
+  // level 73.5 vs 66.2 us, 256: 68.8 vs 64.5, 3-D 128 -> 128: 93.8 vs 87.5): a consumer issues 1.1 transposed 8-byte reads per MFMA
+  // (the convolution consumers 0.6-0.75 16-byte reads) and has no partner wave on its SIMD to cover the 2-way conflicted ones.  Kept as
+  // an option (same results, tested); read per call.
+  const char* pce = getenv("P2I_WGRAD_X6_PC");
+  if (pce != nullptr && atoi(pce) != 0) hipLaunchKernelGGL(wgrad_x6p_kernel, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
+  else hipLaunchKernelGGL(wgrad_x6_kernel, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
   *ns_out = sliced ? ns : 0;
   *slice_out = slice;
   return launch_status();

@@ -652,3 +652,28 @@ def test_x6c_fused_strided_dgrad_matches_f32_engine(ops, monkeypatch):
             monkeypatch.delenv("P2I_X6C_FUSED_KSPLIT")
     finally:
         ops.CONV_ENGINE = old
+
+
+def test_wgrad_x6_producer_consumer_variant_matches_symmetric_kernel(ops, monkeypatch):
+    """wgrad_x6p_kernel (P2I_WGRAD_X6_PC=1: consumers with all nine taps, producers staging; measured slower, not the default) computes
+    exactly what wgrad_x6_kernel computes: same split, same MFMA order per accumulator -> bit-identical slices, incl. bias and t slices."""
+    import ctypes
+    for (cin, cout, sp, k3, s3, p3, bias) in [(64, 128, (16, 32), (1, 3, 3), (1, 1, 1), (0, 1, 1), True),
+                                               (128, 64, (6, 16, 16), (3, 3, 3), (2, 1, 1), (1, 1, 1), True),
+                                               (64, 64, (32, 32), (1, 3, 3), (1, 1, 1), (0, 1, 1), False)]:
+        spec = ops.ConvSpec(cin, cout, k3, s3, p3)
+        xs = (3, cin, *sp)
+        to, ho, wo = spec.out_dims(*((1,) + sp if len(sp) == 2 else sp))
+        ys = (3, cout, ho, wo) if len(sp) == 2 else (3, cout, to, ho, wo)
+        x, dy = _rand(*xs, seed=41).cuda(), _rand(*ys, seed=42).cuda()
+        res = []
+        for pc in ("0", "1"):
+            monkeypatch.setenv("P2I_WGRAD_X6_PC", pc)
+            dwp, db = ops.conv_wgrad(spec, x, dy, want_bias=bias)
+            wplan = (ctypes.c_int * 4)()
+            ops._hip.load().p2i_wgrad_last_plan(wplan)
+            assert wplan[0] == 3, tuple(wplan)
+            res.append((dwp, db))
+        assert torch.equal(res[0][0], res[1][0])
+        if bias:
+            assert rel_err(res[1][1].cpu().numpy(), res[0][1].cpu().numpy()) < 1e-5      # (bias sums are atomic adds in both)
