@@ -656,7 +656,7 @@ def test_x6c_fused_strided_dgrad_matches_f32_engine(ops, monkeypatch):
 
 def test_wgrad_x6_producer_consumer_variant_matches_symmetric_kernel(ops, monkeypatch):
     """wgrad_x6p_kernel (P2I_WGRAD_X6_PC=1: consumers with all nine taps, producers staging; measured slower, not the default) computes
-    exactly what wgrad_x6_kernel computes: same split, same MFMA order per accumulator -> bit-identical slices, incl. bias and t slices."""
+    what wgrad_x6_kernel computes (same split and products, another order of the tile rows), incl. bias and t slices."""
     import ctypes
     for (cin, cout, sp, k3, s3, p3, bias) in [(64, 128, (16, 32), (1, 3, 3), (1, 1, 1), (0, 1, 1), True),
                                                (128, 64, (6, 16, 16), (3, 3, 3), (2, 1, 1), (1, 1, 1), True),
@@ -674,6 +674,7 @@ def test_wgrad_x6_producer_consumer_variant_matches_symmetric_kernel(ops, monkey
             ops._hip.load().p2i_wgrad_last_plan(wplan)
             assert wplan[0] == 3, tuple(wplan)
             res.append((dwp, db))
-        assert torch.equal(res[0][0], res[1][0])
+        # (not bit for bit: the symmetric kernel sums the tile rows of taps 5-8 in another order and the centre tap in two halves)
+        assert rel_err(res[1][0].cpu().numpy(), res[0][0].cpu().numpy()) < 2e-6
         if bias:
             assert rel_err(res[1][1].cpu().numpy(), res[0][1].cpu().numpy()) < 1e-5      # (bias sums are atomic adds in both)
