@@ -756,14 +756,17 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
 // NPW = producer waves: 4 (one per SIMD beside its consumer) or 8 (two per SIMD: the 32-channel tiles' producers are otherwise as busy
 // as their consumers -- stamped: split pass 33 %, load issue 23 %, DMA issue 20 % of their loop, consumers 16 % at the stage barrier;
 // twelve waves leave 170 VGPRs per wave, which only the non-fused 32-channel kernel fits)
-template <int TM, int TPS, bool FUSED = false, bool EPI4 = false, int NPW = 4>
+// TN = position blocks of 32 per consumer wave: 2 (256 positions per workgroup) or 1 (128: layers with so few positions that 32 x 256
+// tiles would need split-K -- the 512-channel level at B = 8 -- get twice the workgroups instead of a zero-filled destination, atomic
+// partial sums and a second activation pass; no epilogue exchange then: a consumer has one accumulator tile)
+template <int TM, int TPS, bool FUSED = false, bool EPI4 = false, int NPW = 4, int TN = 2>
 __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6cGeom g) {
   constexpr int NSTG = 9 / TPS;
   constexpr int NCLS = FUSED ? 4 : 1;                     // FUSED: see X6C_CLS (strided data gradient, four parity classes)
   static_assert(TPS == 3 || TPS == 9, "taps per stage");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MB = 32 * TM, NCW = 4, NTHR = 64 * (NCW + NPW), NPT = 64 * NPW;
-  constexpr int NI = (2 * X6cTile<8>::MAXCSL + NPT - 1) / NPT;            // patch items per producer thread: 3
+  constexpr int NI = (2 * (TN == 2 ? X6cTile<8>::MAXCSL : X6cTile<4>::MAXCSL) + NPT - 1) / NPT;   // patch items per producer thread: 3, 2 or 1
   constexpr int RING = TPS == 9 ? 3 : (TM == 2 ? 4 : 6), LEAD = RING - 1;
   constexpr int WST = 6 * TPS * MB, NWI = WST / 64;
   const int CSl = g.CSl;
@@ -984,29 +987,29 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
 
   // ================================================================= consumers (producers only set up the epilogue geometry here)
   const bool producer = wave >= NCW;
-  const int cw = wave & (NCW - 1);                                       // positions [64 cw, 64 cw + 64); producer w helps consumer w - 4
-  int lane_base[2], pjw_[2], pjh_[2], pjb_[2];
+  const int cw = wave & (NCW - 1);                                       // positions [32 TN cw, 32 TN (cw + 1)); producer w helps consumer w - 4
+  int lane_base[TN], pjw_[TN], pjh_[TN], pjb_[TN];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int pix = cw * 64 + nb * 32 + l31;
+  for (int nb = 0; nb < TN; ++nb) {
+    const int pix = cw * 32 * TN + nb * 32 + l31;
     pjw_[nb] = pix & JWm; pjh_[nb] = (pix >> g.ljw) & JHm; pjb_[nb] = pix >> (g.ljw + g.ljh);
     lane_base[nb] = (pjb_[nb] * g.eH + pjh_[nb]) * g.eW + pjw_[nb] + lhi * CSl;
   }
   int toff[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) toff[t] = g.tap_off[t];
-  f32x16 acc[NCLS][TM][2];
+  f32x16 acc[NCLS][TM][TN];
 #pragma unroll
   for (int q = 0; q < NCLS; ++q)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+      for (int nb = 0; nb < TN; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][i][nb][r] = 0.f;
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-  u32x4c A[3][TM][3], Bv[3][2][3];
+  u32x4c A[3][TM][3], Bv[3][TN][3];
   auto load_tap = [&](const u32x4c* wsl, const u32x4c* pbuf, int tap, int buf) {
     const int tl = tap % TPS;
     const int to = toff[tap];
@@ -1015,7 +1018,7 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
 #pragma unroll
       for (int i = 0; i < TM; ++i) A[buf][i][p] = wsl[((p * TPS + tl) * 2) * MB + 32 * i];
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) Bv[buf][nb][p] = pbuf[lane_base[nb] + p * 2 * CSl + to];
+      for (int nb = 0; nb < TN; ++nb) Bv[buf][nb][p] = pbuf[lane_base[nb] + p * 2 * CSl + to];
     }
   };
   auto mfma_tap = [&](int buf, int slot) {
@@ -1025,13 +1028,13 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < TN; ++nb)
           acc[cl][i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, A[buf][i][PA[q]]), __builtin_bit_cast(bf16x8c, Bv[buf][nb][PB[q]]),
                                                                    acc[cl][i][nb], 0, 0, 0);
   };
   // (reads in consumption order, two per MFMA gap at the front of the tap: measured 2-4 % slower, gpurun_out/r03h/pc2.log)
   auto ilv = [&]() {
-    constexpr int NR = 3 * TM + 6, NM = 12 * TM;
+    constexpr int NR = 3 * TM + 3 * TN, NM = 6 * TM * TN;
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1101,28 +1104,32 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
   // now: all operand reads returned before the last stage barrier), its producer partner (same SIMD) picks it up, so that all
   // eight waves load residual / mask values and store, as in the symmetric kernel
   float* xch = reinterpret_cast<float*>(wbuf);                            // [4 consumers][NCLS][TM][16][64] floats <= 64 KB
-  if (!producer) {
+  if constexpr (TN == 2) {
+    if (!producer) {
 #pragma unroll
-    for (int q = 0; q < NCLS; ++q)
+      for (int q = 0; q < NCLS; ++q)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xch[(((cw * NCLS + q) * TM + i) * 16 + r) * 64 + lane] = acc[q][i][1][r];
-  }
-  __syncthreads();
-  if (wave >= 2 * NCW) return;                                            // (a second producer wave per SIMD has no share in the epilogue)
-  if (producer) {
+          for (int r = 0; r < 16; ++r) xch[(((cw * NCLS + q) * TM + i) * 16 + r) * 64 + lane] = acc[q][i][1][r];
+    }
+    __syncthreads();
+    if (wave >= 2 * NCW) return;                                          // (a second producer wave per SIMD has no share in the epilogue)
+    if (producer) {
 #pragma unroll
-    for (int q = 0; q < NCLS; ++q)
+      for (int q = 0; q < NCLS; ++q)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][i][1][r] = xch[(((cw * NCLS + q) * TM + i) * 16 + r) * 64 + lane];
+          for (int r = 0; r < 16; ++r) acc[q][i][1][r] = xch[(((cw * NCLS + q) * TM + i) * 16 + r) * 64 + lane];
+    }
+  } else {
+    if (producer) return;
   }
   const int dHW = g.dT * g.dH * g.dW;
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    if ((nb == 1) != producer) continue;                                  // consumer: block 0, producer: block 1
+  for (int nb = 0; nb < TN; ++nb) {
+    if (TN == 2 && (nb == 1) != producer) continue;                       // consumer: block 0, producer: block 1
     const int gw = j0w + pjw_[nb], gh = j0h + pjh_[nb], gn = j0b + pjb_[nb];
     const bool pvld = gn < nimg && gh < g.nH && gw < g.nW;
     const int gb_ = gn / g.nT, glt = gn - gb_ * g.nT;
@@ -1136,7 +1143,7 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
                           (g.fused_atomic && blockIdx.z) ? nullptr : g.res, g.mask_y, g.mask_act, g.dst, g.fused_atomic != 0);
     } else if constexpr (EPI4) {
       // 16-byte accesses: this lane's group = positions 4 (lane & 7) .. + 3 of the block (one channel per lane and pass)
-      const int pg = cw * 64 + nb * 32 + 4 * (lane & 7);
+      const int pg = cw * 32 * TN + nb * 32 + 4 * (lane & 7);
       const int qw = pg & JWm, qh = (pg >> g.ljw) & JHm, qb = pg >> (g.ljw + g.ljh);
       const int hw = j0w + qw, hh = j0h + qh, hn = j0b + qb;
       const bool pv4 = hn < nimg && hh < g.nH && hw < g.nW;
@@ -1174,10 +1181,12 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
 // Fewest workgroups for which a tile variant is used (256 CUs; below that the next smaller tile, or the f32 engine).  Read per call
 // (not cached) so that the parity tests can send small layers through these kernels (P2I_X6C_MIN_WG=1).
 static int x6c_min_wg() { const char* e = getenv("P2I_X6C_MIN_WG"); return e ? atoi(e) : 200; }
+static int x6c_pc();
+static int x6p_tn1() { const char* e = getenv("P2I_X6P_TN1"); return e ? atoi(e) : 1; }      // read per call (A/B runs)
 // the fused strided data gradient is taken from 128 workgroups on (half the chip, one round: the 128 -> 256 stride-2 layer at B = 8);
 // its f32 alternative is no faster per workgroup.  P2I_X6C_MIN_WG overrides both thresholds (tests).
 static int x6c_fused_min_wg() { const char* e = getenv("P2I_X6C_MIN_WG"); return e ? atoi(e) : 128; }
-// P2I_X6C_TILE=<NW><TM> (82, 81) forces one variant (tests, tuning)
+// P2I_X6C_TILE=<NW><TM> (82, 81, 41; 41 = the 32 x 128 tile, falling back to 81 where that has no kernel) forces one variant (tests, tuning)
 static int x6c_forced() { const char* e = getenv("P2I_X6C_TILE"); return e ? atoi(e) : 0; }
 
 // P2I_X6C_STAGGER=1: waves 4-7 run their staging work late in the stage (see `staging` in the kernel).  Measured in round 3 at B = 8
@@ -1187,21 +1196,26 @@ static int x6c_stagger() { const char* e = getenv("P2I_X6C_STAGGER"); return e ?
 static int x6c_fused_ksplit() { const char* e = getenv("P2I_X6C_FUSED_KSPLIT"); return e ? atoi(e) : 0; }   // read per call (tests)
 
 struct X6cVariant { int NW, TM; };
-static const X6cVariant kX6cVariants[] = {{8, 2}, {8, 1}};      // in order of per-CU efficiency
+static const X6cVariant kX6cVariants[] = {{8, 2}, {8, 1}, {4, 1}};      // in order of per-CU efficiency ({4, 1}: 32 x 128, x6p only)
 
 struct X6cPick { int v, jb, jh, jw, csl, ksplit; long long wgs; };
 // first variant whose grid fills the chip and whose patch fits; v = -1: none.  When even the 32 x 256 tiles are too few (the
 // 512-channel level at B = 8: 128 tiles) and the epilogue is linear (no activation: split partial sums cannot pass through one),
 // the channel chunks are split over two workgroups per tile that add into a zeroed destination (two addends: order-independent).
-static X6cPick x6c_pick(int B, int nH, int nW, int Cm, int Ck, bool linear_epi) {
-  const int forced = x6c_forced(), min_wg = x6c_min_wg();
+static X6cPick x6c_pick(int B, int nH, int nW, int Cm, int Ck, bool linear_epi, int Ck_slice) {   // Ck = channels x tap slices
+  int forced = x6c_forced();
+  const int min_wg = x6c_min_wg();
+  const bool tn1_ok = x6c_pc() && Ck_slice >= 32;                // the 32 x 128 tile exists as a producer / consumer kernel only
+  if (forced == 41 && !tn1_ok) forced = 81;
   static const int ksplit_on = getenv("P2I_X6C_KSPLIT") ? atoi(getenv("P2I_X6C_KSPLIT")) : 1;
   // candidate order: 64x256, 32x256, then split-K 32x256.  (P2I_X6C_KSPLIT=2 tries split-K 64x256 before plain 32x256: measured 70.8 vs
   // 73.5 us on the 256-channel level, inside the noise, not the default.)
-  static const int order_a[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}}, order_b[4][2] = {{0, 0}, {0, 1}, {1, 0}, {1, 1}};
-  for (int cand = 0; cand < 4; ++cand) {
+  // (round 3: the 32 x 128 tile of the producer / consumer kernel comes before any split-K form; P2I_X6P_TN1=0 removes it)
+  static const int order_a[5][2] = {{0, 0}, {1, 0}, {2, 0}, {1, 1}, {0, 1}}, order_b[5][2] = {{0, 0}, {0, 1}, {1, 0}, {2, 0}, {1, 1}};
+  for (int cand = 0; cand < 5; ++cand) {
       const int v = (ksplit_on == 2 ? order_b : order_a)[cand][0], pass = (ksplit_on == 2 ? order_b : order_a)[cand][1];
       const X6cVariant& t = kX6cVariants[v];
+      if (v == 2 && (!tn1_ok || (forced ? forced != 41 : !x6p_tn1()))) continue;
       if (forced && forced != t.NW * 10 + t.TM) continue;
       if (t.TM == 2 && Cm <= 32 && !forced) continue;      // half of a 64-channel tile would be padding (16 -> 64 layers' data gradient)
       if (pass == 1 && ((ksplit_on != 2 && t.TM != 1) || !ksplit_on || !linear_epi || ((Ck >> 4) & 1) || forced)) continue;
@@ -1244,7 +1258,7 @@ bool x6c_would_take(const p2i_conv_desc* d, bool dgrad, int act_epi) {
   if (nT < 1) return false;
   const int ns = flat ? 1 : (dgrad && d->st == 2 ? 1 : 3);           // fewest slices of a launch (conservative for the chunk-parity test)
   const bool whole = !dgrad || d->st == 1;
-  return x6c_pick(d->B * nT, nH, nW, Cm, ns * Ck, whole).v >= 0;
+  return x6c_pick(d->B * nT, nH, nW, Cm, ns * Ck, whole, Ck).v >= 0;
 }
 
 // second pass of a split-K forward whose epilogue has an activation: y = act(sum of the two partial sums [+ bias, added by split 0])
@@ -1273,14 +1287,14 @@ static void x6c_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
   }
   hipLaunchKernelGGL((patch_gemm_x6c_kernel<NW, TM, FUSED, TPS>), grid, dim3(64 * NW), lds, s, g);
 }
-template <int TM, int TPS, bool FUSED = false, bool EPI4 = false, int NPW = 4>
+template <int TM, int TPS, bool FUSED = false, bool EPI4 = false, int NPW = 4, int TN = 2>
 static void x6p_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW>), grid, dim3(64 * (4 + NPW)), lds, s, g);
+  hipLaunchKernelGGL((patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW, TN>), grid, dim3(64 * (4 + NPW)), lds, s, g);
 }
 // P2I_X6P_NPW=4: one producer wave per SIMD for the 32-channel tiles too (default 8); read per call (A/B runs)
 static int x6p_npw() { const char* e = getenv("P2I_X6P_NPW"); return (e && atoi(e) == 4) ? 4 : 8; }
@@ -1326,7 +1340,7 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   // dst[i] in the same thread, so in-place residual / mask works there; a zero-filled destination would be read back as zeros
   const bool alias = g.dst == g.res || g.dst == g.mask_y;
   const X6cPick pk = x6c_pick((int)nimg, cs.nH, cs.nW, g.Cm, ns * g.Ck,
-                              (n_dst & 3) == 0 && cs.oT == 1 && cs.pT == 0 && cs.nT == g.dT && !alias);
+                              (n_dst & 3) == 0 && cs.oT == 1 && cs.pT == 0 && cs.nT == g.dT && !alias, g.Ck);
   if (pk.v < 0) return 1;
   const unsigned long long sbytes = 4ull * g.B * g.Ck * g.sT * g.sH * g.sW;
   if (sbytes >= 0x7FFFFFF0ull || 4ull * (unsigned long long)n_dst >= 0x7FFFFFF0ull) return 1;
@@ -1355,7 +1369,7 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   for (int i = 0; i < cs.ntaps; ++i) tw_max = cs.tw[i] > tw_max ? cs.tw[i] : tw_max;
   g.wb_bytes = (2u * (unsigned)ntaps_w + (unsigned)tw_max + 1u) * (unsigned)g.Ck * (unsigned)g.CmPad * 2u;
   g.nclass = 1;
-  const int tps = tv.TM == 1 ? x6c_tps1() : 3;
+  const int tps = tv.NW == 4 ? 9 : (tv.TM == 1 ? x6c_tps1() : 3);
   const size_t lds = x6c_lds_bytes(g.CSl, tv.TM, tps);
   const int post_act = (pk.ksplit > 1 && g.act_epi != P2I_ACT_NONE) ? g.act_epi : P2I_ACT_NONE;
   const float* post_res = nullptr;
@@ -1388,6 +1402,7 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   const int pc = x6c_pc();
   if (pc && g.Ck >= 32) {                                 // (a single 16-channel chunk is all prologue and epilogue: symmetric kernel)
     if (tv.TM == 2) { if (k.vec4_epi) x6p_launch<2, 3, false, true>(k, grid, lds, s); else x6p_launch<2, 3>(k, grid, lds, s); }
+    else if (tv.NW == 4) x6p_launch<1, 9, false, false, 8, 1>(k, grid, lds, s);
     else if (tps == 9) { if (x6p_npw() == 8) x6p_launch<1, 9, false, false, 8>(k, grid, lds, s); else x6p_launch<1, 9>(k, grid, lds, s); }
     else x6p_launch<1, 3>(k, grid, lds, s);
   } else if (tv.TM == 2) x6c_launch<8, 2>(k, grid, lds, s);

@@ -61,12 +61,13 @@ def _act_cpu(y, act):
     return {"none": lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.2), "tanh": torch.tanh}[act](y)
 
 
-@pytest.fixture(params=["f32", "x6c", "x6c81", "x6c_sym"])
+@pytest.fixture(params=["f32", "x6c", "x6c81", "x6c41", "x6c_sym"])
 def engine(request, ops, monkeypatch):
     """Both convolution engines are held to the same oracle: the f32-MFMA kernels and the bf16-split kernels (conv_x6c.hip: producer /
     consumer kernels by default, "x6c_sym" = the symmetric ones).  The latter only take layers with >= 200 workgroups by default;
     P2I_X6C_MIN_WG=1 (read per call) sends the small test layers they cover through them too, and P2I_X6C_TILE=<waves><channel tiles>
-    pins one tile variant (default: 82 = 64 x 256 where it fills the chip, else 81 = 32 x 256)."""
+    pins one tile variant (default: 82 = 64 x 256 where it fills the chip, else 81 = 32 x 256, else 41 = 32 x 128 -- producer / consumer
+    kernel only -- before any split-K launch)."""
     old = ops.CONV_ENGINE
     ops.CONV_ENGINE = "f32" if request.param == "f32" else "auto"
     if request.param != "f32":
@@ -133,7 +134,8 @@ def test_x6c_split_k_matches_f32_engine(ops, monkeypatch):
         y32 = ops.conv_fwd(spec, x, wp_f, bias=bias, residual=res)
         dx32 = ops.conv_dgrad(spec, x, wp_d, tuple(x.shape), add=res, mask_y=mk, mask_act=ops.ACT_RELU)
         ops.CONV_ENGINE = "auto"
-        monkeypatch.setenv("P2I_X6C_MIN_WG", "17")        # 16 < 17 <= 32: only the split-K launch fills "the chip"
+        monkeypatch.setenv("P2I_X6C_MIN_WG", "17")        # 16 < 17 <= 32: only the split-K launch fills "the chip" ...
+        monkeypatch.setenv("P2I_X6P_TN1", "0")            # ... once the 32 x 128 tiles (32 workgroups here) are out of the way
         y = ops.conv_fwd(spec, x, wp_f, bias=bias, residual=res)
         assert _last_plan(ops)[5] == 7 and _last_plan(ops)[2] == 2, _last_plan(ops)
         y_again = ops.conv_fwd(spec, x, wp_f, bias=bias, residual=res)
