@@ -220,6 +220,18 @@ int p2i_idw_fwd(const float* vals_src, const float* mask, const float* grid_x, c
                 const float* grid_z, float* out, int32_t* pt_pos, int32_t* pt_count, int32_t* frame_count,
                 int32_t* row_start, float* pt_xyzn, int32_t* sel_idx, float* sel_w, int B, int T, int H, int W, float tau,
                 void* stream);
+/* The same result from a two-pass search (round 3).  The reference's scan order matters only where the 4th and 5th smallest
+ * computed distances of a voxel are EQUAL (which tied point is kept depends on the heap's history); everywhere else the set of
+ * selected points is the four nearest, whatever the order.  Pass 1 searches outwards from the voxel (own frame and rows first:
+ * ~10 % of the distance evaluations of the index-order scan) and lists the voxels it finds tied; pass 2 replays the reference's
+ * scan for those only (3-4 % with one gauge mask shared by all frames).  Ties among the four selected points permute equal
+ * weights in the 4-term output sum (<= 1 ulp of the output; sel_idx / sel_w order may differ there).
+ *   amb int32 [B*(Q+1+ceil(Q/256))]: per sample the number of listed voxels, the lists of pass 1's workgroups (256 slots each)
+ *       and their lengths / prefix sums (work buffer). */
+int p2i_idw_fwd_ws(const float* vals_src, const float* mask, const float* grid_x, const float* grid_y,
+                   const float* grid_z, float* out, int32_t* pt_pos, int32_t* pt_count, int32_t* frame_count,
+                   int32_t* row_start, float* pt_xyzn, int32_t* sel_idx, float* sel_w, int32_t* amb, int B, int T, int H, int W,
+                   float tau, void* stream);
 int p2i_idw_bwd(const float* dout, const int32_t* pt_pos, const int32_t* pt_count, const int32_t* sel_idx,
                 const float* sel_w, float* dvals_src, int B, int T, int H, int W, void* stream);
 

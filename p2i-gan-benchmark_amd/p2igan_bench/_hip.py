@@ -55,6 +55,7 @@ SIGNATURES = {
     "p2i_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "p2i_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "p2i_idw_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "p2i_idw_fwd_ws": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "p2i_idw_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "p2i_pooldup_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "p2i_pooldup_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],

@@ -738,7 +738,7 @@ def _grid_tables(T, H, W, device):
     return _LINSPACE[key]
 
 
-def idw_fwd(vals_src, mask, tau=0.05, save=True):
+def idw_fwd(vals_src, mask, tau=0.05, save=True, _amb_out=None):
     """vals_src, mask: (B,T,H,W).  Returns out and the saved selection (pt_pos, sel_idx, sel_w)."""
     lib = _hip.load()
     B, T, H, W = vals_src.shape
@@ -756,6 +756,14 @@ def idw_fwd(vals_src, mask, tau=0.05, save=True):
     sel_idx = torch.empty(B * Q * 4, device=dev, dtype=torch.int32) if save else None
     sel_w = torch.empty(B * Q * 4, device=dev, dtype=torch.float32) if save else None
     _chk(vals_src, mask)
+    if _os.environ.get("P2I_IDW_FAST", "1") != "0":     # two-pass search (p2i_hip.h); "0": the reference's scan for every voxel (A/B, tests)
+        amb = torch.empty(B * (Q + 1 + (Q + 255) // 256), device=dev, dtype=torch.int32)
+        _hip.check(lib.p2i_idw_fwd_ws(_ptr(vals_src), _ptr(mask), _ptr(gx), _ptr(gy), _ptr(gz), _ptr(out), _ptr(pt_pos), _ptr(pt_count),
+                                      _ptr(frame_count), _ptr(row_start), _ptr(pt_xyzn), _ptr(sel_idx), _ptr(sel_w), _ptr(amb), B, T, H, W,
+                                      float(tau), _stream()), "p2i_idw_fwd_ws")
+        if _amb_out is not None:                       # tests: the per-sample count of voxels left to the replay pass
+            _amb_out.append(amb)
+        return out, (pt_pos, pt_count, sel_idx, sel_w)
     _hip.check(lib.p2i_idw_fwd(_ptr(vals_src), _ptr(mask), _ptr(gx), _ptr(gy), _ptr(gz), _ptr(out), _ptr(pt_pos), _ptr(pt_count),
                                _ptr(frame_count), _ptr(row_start), _ptr(pt_xyzn), _ptr(sel_idx), _ptr(sel_w), B, T, H, W, float(tau), _stream()),
                "p2i_idw_fwd")

@@ -356,6 +356,39 @@ def test_idw_matches_oracle_and_golden(ops, kind, golden):
     assert rel_err(dv.cpu().numpy(), src.grad.numpy()) < TOL_WGRAD
 
 
+@pytest.mark.parametrize("kind,shape", [("gauge", (2, 16, 64, 64)), ("gauge", (1, 16, 40, 96)), ("block", (2, 16, 64, 64)), ("pergauge", (2, 8, 48, 48))])
+def test_idw_two_pass_search_equals_index_order_scan(ops, monkeypatch, kind, shape):
+    """ops.idw_fwd's default (outward search + replay of the tied voxels, p2i_idw_fwd_ws) against the single-kernel replay of the
+    reference's scan (P2I_IDW_FAST=0, the kernel the oracle / golden tests pinned in rounds 1-2): the same four points for every voxel
+    -- compared as sets: ties among the four may come out in another order -- and outputs equal to summation order."""
+    from p2igan_bench.utils import seeded
+    B, T, H, W = shape
+    if kind == "gauge":                      # one mask for every frame: the (t-1)/(t+1) ties the replay pass exists for
+        mk = seeded.gauge_mask(H, W, 40).reshape(1, 1, H, W).expand(B, T, H, W).contiguous()
+    elif kind == "block":
+        mk = seeded.block_mask(H, W, 8, seed=5).reshape(1, 1, H, W).expand(B, T, H, W).contiguous()
+    else:                                    # a different mask per frame and sample, some frames empty
+        g = torch.Generator().manual_seed(11)
+        mk = (torch.rand(B, T, H, W, generator=g) < 0.004).float()
+        mk[:, 2] = 0
+        mk[0, 5] = 0
+    src = _rand(B, T, H, W, seed=3).abs().cuda()
+    mk = mk.cuda()
+    amb = []
+    out, (pt_pos, pt_count, sel, selw) = ops.idw_fwd(src, mk, _amb_out=amb)
+    counts = amb[0].view(B, -1)[:, 0].cpu()
+    monkeypatch.setenv("P2I_IDW_FAST", "0")
+    out0, (pt_pos0, pt_count0, sel0, selw0) = ops.idw_fwd(src, mk)
+    assert torch.equal(pt_pos[: int(pt_count[0])], pt_pos0[: int(pt_count0[0])]) and torch.equal(pt_count, pt_count0)
+    a, b = sel.view(-1, 4).sort(dim=1).values, sel0.view(-1, 4).sort(dim=1).values
+    assert torch.equal(a, b), f"{int((a != b).any(dim=1).sum())} voxels select other points"
+    assert float((out - out0).abs().max()) <= 4e-7 * float(out0.abs().max())
+    assert float((selw.view(-1, 4).sort(dim=1).values - selw0.view(-1, 4).sort(dim=1).values).abs().max()) <= 1e-6
+    if kind == "gauge":
+        assert int(counts.min()) > 0                             # the replay pass had voxels to decide
+    assert int(counts.max()) < T * H * W // 4, counts
+
+
 def test_idw_empty_mask(ops):
     src = _rand(1, 16, 8, 8, seed=1).cuda()
     out, _ = ops.idw_fwd(src, torch.zeros_like(src))

@@ -16,4 +16,7 @@ for name, m in (("gauge79", seeded.gauge_mask(128, 128, 79)), ("block10", seeded
     for _ in range(10):
         out, _ = ops.idw_fwd(x, mm)
     e1.record(); torch.cuda.synchronize()
-    print(f"B={B} {name}: {e0.elapsed_time(e1) * 100:.1f} us  checksum {float(out.double().sum()):.6f}", flush=True)
+    amb = []
+    ops.idw_fwd(x, mm, _amb_out=amb)
+    und = ("  undecided voxels/sample (replay pass): %s of %d" % (amb[0].view(B, -1)[:, 0].tolist(), 16 * 128 * 128)) if amb else ""
+    print(f"B={B} {name}: {e0.elapsed_time(e1) * 100:.1f} us  checksum {float(out.double().sum()):.6f}{und}", flush=True)
