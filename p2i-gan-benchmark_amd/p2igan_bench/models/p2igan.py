@@ -205,9 +205,38 @@ def _grad_target(prm, inplace):
     return prm.grad if inplace else None
 
 
-def generator_forward(net: "P2IGenerator", masked_frames, masks, need_grad: bool):
+def generator_prepare(net: "P2IGenerator", b: int, h: int, w: int):
+    """Everything of a training forward that depends on the PARAMETERS only: the DO-Conv folds of all levels, the 1x1 packs and the
+    bf16 split images the conv calls will ask for.  TrainEngine runs this on a side stream while the main stream computes the
+    attention block and the IDW (latency-bound kernels that leave most of the chip idle); generator_forward(prep=...) then finds
+    every weight ready.  Returns the dict generator_forward consumes."""
+    t, BASE_CH = net.length, net.base
+    prep = {"folded": {}, "up": {}}
+    cin = _doconv_of(net.Convsin[0])
+    prep["wp_in"] = ops.doconv_fold(*cin.tensors(), BASE_CH, t, 4, 3, identity_rep=4, need_d=True)
+    for lvl in (3, 2, 1, 0):
+        ch = BASE_CH << lvl
+        convs = [_doconv_of(m) for rb in net.Decoder[lvl].layers for m in (rb.main[0], rb.main[1])]
+        wps = ops.doconv_fold_batched([cv.tensors() for cv in convs], ch, ch, need_d=True)
+        for cv, wp in zip(convs, wps):
+            prep["folded"][id(cv)] = wp
+        d = _spec2d(ch, ch, 3).desc(b, 1, h >> lvl, w >> lvl)
+        ops._x6s_of(wps[0][0], d, False, ACT_RELU)       # splits the level's whole forward / data-gradient stacks now
+        ops._x6s_of(wps[0][1], d, True)                   # (no-ops where the layer will not run on the bf16-split kernels)
+    for i in (2, 1, 0):
+        up = net.UP[i]
+        cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
+        prep["up"][i] = ops.weight_pack(up.proj.weight.reshape(cout_, cin_, 1), need_d=True)
+    cout = _doconv_of(net.ConvsOut[0])
+    prep["wp_out"] = ops.doconv_fold(*cout.tensors(), t, BASE_CH, 4, 1, need_d=True)
+    return prep
+
+
+def generator_forward(net: "P2IGenerator", masked_frames, masks, need_grad: bool, prep=None, weights_ready=None):
     """P2IGenerator.forward (p2igan.py:72-112) as a plain function: returns (frames (B,T,1,H,W), saved state or None).
-    Sequences the kernels of p2igan_bench.ops; no autograd involved (TrainEngine calls this directly, _GeneratorFn wraps it)."""
+    Sequences the kernels of p2igan_bench.ops; no autograd involved (TrainEngine calls this directly, _GeneratorFn wraps it).
+    prep: generator_prepare's result (training only); weights_ready(): called once, right before the first kernel that reads a
+    prepared weight (TrainEngine: joins the side stream the preparation runs on)."""
     b, t, c, h, w = masked_frames.shape
     BASE_CH = net.base
     if c != 1 or t != net.length:
@@ -227,8 +256,10 @@ def generator_forward(net: "P2IGenerator", masked_frames, masks, need_grad: bool
     a = ops.attn_fwd(x0, att[0].weight, att[0].bias, att[1].weight, att[1].bias)
     idw, sel = ops.idw_fwd(a, mk, tau=0.05, save=need_grad)
     del a
+    if weights_ready is not None:
+        weights_ready()
     cin = _doconv_of(net.Convsin[0])
-    wp_in = fold(cin, BASE_CH, t, 4, 3, identity_rep=4)
+    wp_in = prep["wp_in"] if prep is not None else fold(cin, BASE_CH, t, 4, 3, identity_rep=4)
     spec_in = _spec2d(t, BASE_CH, 3)
     x_ = ops.conv_fwd(spec_in, idw, wp_in[0])
     x_2 = ops.pooldup_fwd(x_)
@@ -239,8 +270,8 @@ def generator_forward(net: "P2IGenerator", masked_frames, masks, need_grad: bool
         ch = BASE_CH << lvl
         spec = _spec2d(ch, ch, 3)
         rec = []
-        folded = {}
-        if need_grad:                                # the level's 2*num_res same-shape folds in ONE launch
+        folded = prep["folded"] if prep is not None else {}
+        if need_grad and prep is None:               # the level's 2*num_res same-shape folds in ONE launch
             convs = [_doconv_of(m) for rb in net.Decoder[lvl].layers for m in (rb.main[0], rb.main[1])]
             for cv, wp in zip(convs, ops.doconv_fold_batched([cv.tensors() for cv in convs], ch, ch, need_d=True)):
                 folded[id(cv)] = wp
@@ -259,7 +290,7 @@ def generator_forward(net: "P2IGenerator", masked_frames, masks, need_grad: bool
         cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
         u = ops.upmod_fwd(hcur, up.pos)
         pack = lambda: ops.weight_pack(up.proj.weight.reshape(cout_, cin_, 1), need_d=need_grad)
-        wp = pack() if need_grad else net._cached(id(up), (up.proj.weight,), pack)
+        wp = prep["up"][i] if prep is not None else (pack() if need_grad else net._cached(id(up), (up.proj.weight,), pack))
         r = ops.conv_fwd(_spec2d(cin_, cout_, 1), u, wp[0], bias=up.proj.bias, act=ACT_RELU)
         return r, (hcur, u, r, wp[1])
 
@@ -272,7 +303,7 @@ def generator_forward(net: "P2IGenerator", masked_frames, masks, need_grad: bool
     res3, up0 = uppos(0, h1)
     h0, rec0 = eblock(0, res3)
     cout = _doconv_of(net.ConvsOut[0])
-    wp_out = fold(cout, t, BASE_CH, 4, 1)
+    wp_out = prep["wp_out"] if prep is not None else fold(cout, t, BASE_CH, 4, 1)
     spec_out = _spec2d(BASE_CH, t, 1)
     z = ops.conv_fwd(spec_out, h0, wp_out[0], act=ACT_TANH)
     if net.debug_taps is not None:
@@ -519,14 +550,12 @@ class P2IDiscriminator(nn.Module):
         return _DiscriminatorFn.apply(self, x, *params)
 
 
-def discriminator_forward(net: "P2IDiscriminator", x, need_x: bool, need_p: bool, pool: bool = False):
-    """P2IDiscriminator.forward (p2igan.py:157-173) incl. the spectral-norm power iteration, as a plain function: returns
-    (logits (B, H/4*W/4), saved context or None).  pool=True (TrainEngine only: at most three forwards pending): the packed
-    weights live in a round-robin of four reusable buffers instead of a fresh zero-filled one per call."""
-    b, t, c, h, w = x.shape
-    if c * t != net.in_channels:
-        raise RuntimeError(f"discriminator expects {net.in_channels} frames, got {t}x{c}")
-    xin = x.contiguous().float()
+def discriminator_prepare(net: "P2IDiscriminator", xshape, device, need_x: bool, need_p: bool, pool: bool = False):
+    """The parameter-only part of one discriminator forward: ONE spectral-norm power iteration of all ten layers (u, v updated in
+    place, as torch does in every training forward), weight / sigma packed for the conv engine, and the bf16 split images.  Calls
+    must come in the order of the forwards they serve (each advances u, v).  TrainEngine prepares the fake and the real pass of
+    the D step on a side stream while the generator's forward runs; discriminator_forward(prep=...) consumes the result."""
+    b, t, c, h, w = xshape
     l2, l3 = net.layers()
     training = net.training
 
@@ -543,12 +572,12 @@ def discriminator_forward(net: "P2IDiscriminator", x, need_x: bool, need_p: bool
     need_d = need_x or need_p
     pbuf = None
     if pool:
-        bufs = net._pack_pool.setdefault((need_d, str(xin.device)), [None] * 4)
+        bufs = net._pack_pool.setdefault((need_d, str(device)), [None] * 4)
         net._pack_turn = (net._pack_turn + 1) % 4
         if bufs[net._pack_turn] is None:
             tot = sum(wf.shape[2] * wf.shape[1] * ops.pad32(wf.shape[0]) + (wf.shape[2] * wf.shape[0] * ops.pad32(wf.shape[1]) if need_d else 0)
                       for wf in wflats)
-            bufs[net._pack_turn] = ops.zero_(torch.empty(tot, device=xin.device, dtype=torch.float32))
+            bufs[net._pack_turn] = ops.zero_(torch.empty(tot, device=device, dtype=torch.float32))
         pbuf = bufs[net._pack_turn]
     packed = ops.weight_pack_batched(wflats, sig_all, need_d=need_d, buf=pbuf)
     pack_of = {id(m): pk for m, pk in zip(l2 + l3, packed)}
@@ -565,10 +594,28 @@ def discriminator_forward(net: "P2IDiscriminator", x, need_x: bool, need_p: bool
         net._x6_wants[wkey] = wants
     tens = [t_ for pk in packed for t_ in pk]
     if pool:
-        sb = net._pack_pool.setdefault(("x6", need_d, str(xin.device)), [None] * 4)
+        sb = net._pack_pool.setdefault(("x6", need_d, str(device)), [None] * 4)
         sb[net._pack_turn] = ops.x6_presplit(tens, wants, buf=sb[net._pack_turn])
     else:
         ops.x6_presplit(tens, wants)
+    return dict(sig_of=sig_of, uv_of=uv_of, pack_of=pack_of, key=(tuple(xshape), need_x, need_p))
+
+
+def discriminator_forward(net: "P2IDiscriminator", x, need_x: bool, need_p: bool, pool: bool = False, prep=None):
+    """P2IDiscriminator.forward (p2igan.py:157-173) incl. the spectral-norm power iteration, as a plain function: returns
+    (logits (B, H/4*W/4), saved context or None).  pool=True (TrainEngine only: at most three forwards pending): the packed
+    weights live in a round-robin of four reusable buffers instead of a fresh zero-filled one per call.  prep: this forward's
+    discriminator_prepare result when the caller has run it ahead of time."""
+    b, t, c, h, w = x.shape
+    if c * t != net.in_channels:
+        raise RuntimeError(f"discriminator expects {net.in_channels} frames, got {t}x{c}")
+    xin = x.contiguous().float()
+    l2, l3 = net.layers()
+    if prep is None:
+        prep = discriminator_prepare(net, (b, t, c, h, w), xin.device, need_x, need_p, pool)
+    elif prep["key"] != ((b, t, c, h, w), need_x, need_p):
+        raise RuntimeError("discriminator_forward: prep was made for another call")
+    sig_of, uv_of, pack_of = prep["sig_of"], prep["uv_of"], prep["pack_of"]
 
     def branch(layers, specs, inp):
         recs, cur = [], inp
