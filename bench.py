@@ -400,10 +400,15 @@ def main():
         _p2igan.SIDE_WGRAD = side_saved
         # BASELINE.json's second figure, "G-step ms" (G fwd, rec loss, D fwd on fake, adv loss, G bwd incl. the
         # dgrad through D, Adam-G): un-instrumented steps with four phase events each
+        # (the step's side-stream overlap is off here: with it D's real-pass forward runs DURING the generator's forward and the
+        # phase boundaries on the main stream would charge it to the G step)
+        overlap_saved = getattr(eng, "prep_overlap", False)
+        eng.prep_overlap = False
         if rank == 0 and eng.use_gan:
             eng.phase_marks = []
         for _ in range(nprof):
             eng.train_step(frames, masked, masks)
+        eng.prep_overlap = overlap_saved
         if rank == 0 and eng.use_gan:
             torch.cuda.synchronize()
             m, g_ms, d_ms = eng.phase_marks, 0.0, 0.0
@@ -413,6 +418,7 @@ def main():
             eng.phase_marks = None
             extra["g_step_ms"] = round(g_ms / nprof, 3)
             extra["d_step_ms"] = round(d_ms / nprof, 3)
+            extra["phase_note"] = "g_step_ms / d_step_ms: main-stream phase events of steps run WITHOUT the side-stream overlap of D's real pass / weight preparation (P2I_PREP_OVERLAP=0); ms_per_step is with it"
         eng._graph = graph_saved
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the conv-engine instance with the largest share of the step (single-kernel keys only)

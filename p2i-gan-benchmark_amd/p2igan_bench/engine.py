@@ -201,26 +201,32 @@ class TrainEngine:
             # Parameter-only work of the step's first three forwards -- G's DO-Conv folds / packs / bf16 splits, and the power
             # iteration + pack + split of D's fake and real pass -- goes to a side stream and runs beside the attention block and
             # the IDW, whose latency-bound kernels leave most of the chip idle (P2I_PREP_OVERLAP=0: inline, as before round 3).
+            # D's REAL pass needs nothing of the generator either: its whole forward follows on the side stream and shares the chip
+            # with the generator's convolutions (fills their tails); the main stream joins before the D loss.
             side = net_fns._side_of(G, frames.device) if (self.prep_overlap and frames.is_cuda) else None
-            gprep, dprep_f, dprep_r, ready = None, None, None, None
+            gprep, dprep_f, real_out, ready = None, None, None, None
             if side is not None:
                 b_, t_, c_, h_, w_ = masked.shape
                 gprep = side.run(lambda: net_fns.generator_prepare(G, b_, h_, w_))
+                ev_g = side.mark()
+                ready = lambda: torch.cuda.current_stream().wait_event(ev_g)
                 if self.use_gan:
                     D.train()
                     dprep_f = side.run(lambda: net_fns.discriminator_prepare(D, tuple(masked.shape), frames.device, False, True, pool=True))
                     dprep_r = side.run(lambda: net_fns.discriminator_prepare(D, tuple(frames.shape), frames.device, False, True, pool=True))
-                ready = side.join
+                    real_out = side.run(lambda: net_fns.discriminator_forward(D, frames, need_x=False, need_p=True, pool=True, prep=dprep_r), frames)
             preds, S = net_fns.generator_forward(G, masked, masks, need_grad=True, prep=gprep, weights_ready=ready)
             out3, dpred = ops.recloss(preds.contiguous(), frames.contiguous().float(), self.rec_loss.k1_alpha)
             out = {"rec": out3[2], "pool": out3[0], "reg": out3[1]}
             self._mark()
             dgen = dpred
             loss_g = out3[2:3]
+            if side is not None:
+                side.join()
             if self.use_gan:
                 D.train()
                 lf, cf = net_fns.discriminator_forward(D, preds, need_x=False, need_p=True, pool=True, prep=dprep_f)
-                lr_, cr = net_fns.discriminator_forward(D, frames, need_x=False, need_p=True, pool=True, prep=dprep_r)
+                lr_, cr = real_out if real_out is not None else net_fns.discriminator_forward(D, frames, need_x=False, need_p=True, pool=True)
                 loss_d, dlr, dlf = ops.gan_loss_d(lr_, lf, self.gan_type, self.real_label, self.fake_label)
                 self.dp.zero_grad()
                 net_fns.discriminator_backward(D, cf, dlf, need_x=False, inplace=True, accumulate=False)

@@ -259,6 +259,12 @@ class SideStream:
         self.pending = True
         return out
 
+    def mark(self):
+        """An event after everything enqueued on the side stream so far (the main stream can wait for PART of the side work)."""
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
     def join(self):
         if self.pending:
             ev = torch.cuda.Event()
