@@ -201,8 +201,8 @@ class TrainEngine:
             # Parameter-only work of the step's first three forwards -- G's DO-Conv folds / packs / bf16 splits, and the power
             # iteration + pack + split of D's fake and real pass -- goes to a side stream and runs beside the attention block and
             # the IDW, whose latency-bound kernels leave most of the chip idle (P2I_PREP_OVERLAP=0: inline, as before round 3).
-            # D's REAL pass needs nothing of the generator either: its whole forward follows on the side stream and shares the chip
-            # with the generator's convolutions (fills their tails); the main stream joins before the D loss.
+            # D's REAL pass needs nothing of the generator either: its forward and backward follow on the side stream and share the
+            # chip with the generator's convolutions (fill their tails); the main stream joins before D's fake pass.
             side = net_fns._side_of(G, frames.device) if (self.prep_overlap and frames.is_cuda) else None
             gprep, dprep_f, real_out, ready = None, None, None, None
             if side is not None:
@@ -214,7 +214,23 @@ class TrainEngine:
                     D.train()
                     dprep_f = side.run(lambda: net_fns.discriminator_prepare(D, tuple(masked.shape), frames.device, False, True, pool=True))
                     dprep_r = side.run(lambda: net_fns.discriminator_prepare(D, tuple(frames.shape), frames.device, False, True, pool=True))
-                    real_out = side.run(lambda: net_fns.discriminator_forward(D, frames, need_x=False, need_p=True, pool=True, prep=dprep_r), frames)
+
+
+                    def real_pass():
+                        # forward AND backward of the real half of the D loss: every GAN loss here is a sum of a real and a fake
+                        # term, so d loss_d / d logits_real needs the real logits only (p2i_gan_loss with the real logits in both
+                        # slots gives exactly that gradient); the fake half adds its weight gradients later -- two addends, the
+                        # same sum in either order
+                        lr2, cr2 = net_fns.discriminator_forward(D, frames, need_x=False, need_p=True, pool=True, prep=dprep_r)
+                        if capturing:                    # (hipGraph capture: the backward's own side stream nested in this one ends
+                            return lr2, cr2              # capture_end in a segmentation fault on ROCm 7.2 -- forward only then)
+                        _, dlr2, _ = ops.gan_loss_d(lr2, lr2, self.gan_type, self.real_label, self.fake_label)
+                        self.dp.zero_grad()
+                        net_fns.discriminator_backward(D, cr2, dlr2, need_x=False, inplace=True, accumulate=False)
+                        return lr2, None
+
+                    capturing = torch.cuda.is_current_stream_capturing()
+                    real_out = side.run(real_pass, frames)
             preds, S = net_fns.generator_forward(G, masked, masks, need_grad=True, prep=gprep, weights_ready=ready)
             out3, dpred = ops.recloss(preds.contiguous(), frames.contiguous().float(), self.rec_loss.k1_alpha)
             out = {"rec": out3[2], "pool": out3[0], "reg": out3[1]}
@@ -226,12 +242,18 @@ class TrainEngine:
             if self.use_gan:
                 D.train()
                 lf, cf = net_fns.discriminator_forward(D, preds, need_x=False, need_p=True, pool=True, prep=dprep_f)
-                lr_, cr = real_out if real_out is not None else net_fns.discriminator_forward(D, frames, need_x=False, need_p=True, pool=True)
-                loss_d, dlr, dlf = ops.gan_loss_d(lr_, lf, self.gan_type, self.real_label, self.fake_label)
-                self.dp.zero_grad()
-                net_fns.discriminator_backward(D, cf, dlf, need_x=False, inplace=True, accumulate=False)
-                net_fns.discriminator_backward(D, cr, dlr, need_x=False, inplace=True, accumulate=True)
-                del cf, cr
+                if real_out is not None and real_out[1] is None:      # the real half is done (forward and backward, on the side stream)
+                    lr_ = real_out[0]
+                    loss_d, _, dlf = ops.gan_loss_d(lr_, lf, self.gan_type, self.real_label, self.fake_label)
+                    net_fns.discriminator_backward(D, cf, dlf, need_x=False, inplace=True, accumulate=True)
+                    del cf
+                else:
+                    lr_, cr = real_out if real_out is not None else net_fns.discriminator_forward(D, frames, need_x=False, need_p=True, pool=True)
+                    loss_d, dlr, dlf = ops.gan_loss_d(lr_, lf, self.gan_type, self.real_label, self.fake_label)
+                    self.dp.zero_grad()
+                    net_fns.discriminator_backward(D, cf, dlf, need_x=False, inplace=True, accumulate=False)
+                    net_fns.discriminator_backward(D, cr, dlr, need_x=False, inplace=True, accumulate=True)
+                    del cf, cr
                 if self.distributed:
                     _allreduce_mean(self.dp.grad, self.world)
                 self.opt_d.step()
