@@ -188,6 +188,7 @@ def _doconv_of(holder):      # BasicConv holder -> DOConv params
 import os as _os
 
 SIDE_WGRAD = _os.environ.get("P2I_SIDE_WGRAD", "1") != "0"
+LATE_JOIN = _os.environ.get("P2I_LATE_JOIN", "1") != "0"       # generator_backward: weight-side kernels on the side stream, one join
 
 
 def _side_of(net, device):
@@ -339,15 +340,25 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False, on_l
         tgt = arena.take(spec.wp_f_shape())                        # carve on the main thread of control: the arena is not stream-safe
         return side.run(lambda: ops.conv_wgrad(spec, x, dy, dwp_out=tgt, **kw), x, dy)
 
+    # The kernels that CONSUME packed weight gradients (DO-Conv fold backward, 1x1 unpack) read weights and wgrad results only:
+    # they follow the wgrads on the side stream, so the data-gradient chain never waits for a weight gradient (round 2 joined
+    # the streams at every level, 1x1 projection and at both ends: nine stalls of one wgrad each); one join at the very end.
+    late = side is not None and LATE_JOIN
+
+    def weight_side(fn):
+        if late:
+            return side.run(fn)
+        if side is not None:
+            side.join()
+        return fn()
+
     dz = dout.reshape(b, t, h, w).contiguous().float()
     # ---- ConvsOut (grouped 1x1, dense-lowered) + tanh
     spec_out = _spec2d(BASE_CH, t, 1)
     cout = _doconv_of(net.ConvsOut[0])
     dz = ops.act_bwd(dz, S["z"], ACT_TANH)                      # * (1 - z^2): prologue-free kernels below
     dwp, _ = wgrad(spec_out, S["h0"], dz)
-    if side is not None:
-        side.join()
-    gw, _ = ops.doconv_fold_bwd(dwp, *cout.tensors(), t, BASE_CH, 4, 1, out=(cout.W.grad, None) if inplace else None)
+    gw, _ = weight_side(lambda: ops.doconv_fold_bwd(dwp, *cout.tensors(), t, BASE_CH, 4, 1, out=(cout.W.grad, None) if inplace else None))
     if not inplace:
         grads[id(cout.W)] = gw
     dh = ops.conv_dgrad(spec_out, dz, S["wp_out_d"], tuple(S["h0"].shape))
@@ -366,14 +377,17 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False, on_l
             pend.append((dwp1, c1))
             dh = ops.conv_dgrad(spec, dy1, w1d, tuple(hin.shape), add=dh)                     # + skip path
         outs = ([cv.W.grad for _, cv in pend], [cv.D.grad for _, cv in pend]) if inplace else None
-        if side is not None:
-            side.join()                               # the level's weight gradients are complete
-        dWs, dDs = ops.doconv_fold_bwd_batched([g_ for g_, _ in pend], [cv.tensors() for _, cv in pend], ch, ch, outs=outs)
+
+        def fold_level():                             # behind the level's weight gradients
+            r_ = ops.doconv_fold_bwd_batched([g_ for g_, _ in pend], [cv.tensors() for _, cv in pend], ch, ch, outs=outs)
+            if inplace and on_level_done is not None:
+                on_level_done(lvl)                    # (on the stream that completed the level's gradients)
+            return r_
+
+        dWs, dDs = weight_side(fold_level)
         if not inplace:
             for (_, cv), dW_, dD_ in zip(pend, dWs, dDs):
                 grads[id(cv.W)], grads[id(cv.D)] = dW_, dD_
-        elif on_level_done is not None:
-            on_level_done(lvl)
         return dh
 
     def uppos_bwd(i, dr):
@@ -383,9 +397,7 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False, on_l
         spec = _spec2d(cin_, cout_, 1)
         dr = ops.act_bwd(dr, r, ACT_RELU)                       # * relu'(r) once, for wgrad and dgrad
         dwp, db = wgrad(spec, u, dr, want_bias=True, db_out=_grad_target(up.proj.bias, inplace))
-        if side is not None:
-            side.join()
-        gw_ = ops.weight_unpack_grad(dwp, up.proj.weight.reshape(cout_, cin_, 1), out=_grad_target(up.proj.weight, inplace))
+        gw_ = weight_side(lambda: ops.weight_unpack_grad(dwp, up.proj.weight.reshape(cout_, cin_, 1), out=_grad_target(up.proj.weight, inplace)))
         du = ops.conv_dgrad(spec, dr, wpd, tuple(u.shape))
         dx, dpos = ops.upmod_bwd(hin, up.pos, du, dpos_out=_grad_target(up.pos, inplace))
         if not inplace:
@@ -408,9 +420,7 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False, on_l
     spec_in = _spec2d(t, BASE_CH, 3)
     cin = _doconv_of(net.Convsin[0])
     dwp, _ = wgrad(spec_in, S["idw"], dx_)
-    if side is not None:
-        side.join()
-    gW, gD = ops.doconv_fold_bwd(dwp, *cin.tensors(), BASE_CH, t, 4, 3, out=(cin.W.grad, cin.D.grad) if inplace else None)
+    gW, gD = weight_side(lambda: ops.doconv_fold_bwd(dwp, *cin.tensors(), BASE_CH, t, 4, 3, out=(cin.W.grad, cin.D.grad) if inplace else None))
     if not inplace:
         grads[id(cin.W)], grads[id(cin.D)] = gW, gD
     didw = ops.conv_dgrad(spec_in, dx_, S["wp_in_d"], tuple(S["idw"].shape))
@@ -421,6 +431,8 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False, on_l
     if not inplace:
         for prm, gr in zip(prm4, g):
             grads[id(prm)] = gr.reshape(prm.shape)
+    if side is not None:
+        side.join()
     return grads
 
 
