@@ -232,16 +232,22 @@ class TrainEngine:
                     capturing = torch.cuda.is_current_stream_capturing()
                     real_out = side.run(real_pass, frames)
             preds, S = net_fns.generator_forward(G, masked, masks, need_grad=True, prep=gprep, weights_ready=ready)
-            out3, dpred = ops.recloss(preds.contiguous(), frames.contiguous().float(), self.rec_loss.k1_alpha)
+            if side is not None and self.use_gan:
+                # the reconstruction loss (three short latency-bound kernels) is needed at the generator's backward only: it queues
+                # behind D's real half on the side stream while D's fake forward starts on the main stream right away
+                out3, dpred = side.run(lambda: ops.recloss(preds.contiguous(), frames.contiguous().float(), self.rec_loss.k1_alpha), preds, frames)
+            else:
+                out3, dpred = ops.recloss(preds.contiguous(), frames.contiguous().float(), self.rec_loss.k1_alpha)
             out = {"rec": out3[2], "pool": out3[0], "reg": out3[1]}
             self._mark()
             dgen = dpred
             loss_g = out3[2:3]
-            if side is not None:
-                side.join()
             if self.use_gan:
                 D.train()
                 lf, cf = net_fns.discriminator_forward(D, preds, need_x=False, need_p=True, pool=True, prep=dprep_f)
+            if side is not None:
+                side.join()                                  # D's real half (and the reconstruction loss) are complete
+            if self.use_gan:
                 if real_out is not None and real_out[1] is None:      # the real half is done (forward and backward, on the side stream)
                     lr_ = real_out[0]
                     loss_d, _, dlf = ops.gan_loss_d(lr_, lf, self.gan_type, self.real_label, self.fake_label)
