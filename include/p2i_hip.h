@@ -104,7 +104,7 @@ int p2i_conv_wgrad_ws(const p2i_conv_desc* d, const float* x, const float* dy, c
  * fp32-MFMA kernels, exactly as p2i_conv_fwd / p2i_conv_dgrad would; the choice is the library's.
  * `wsplit`: caller-owned scratch of 3*ntaps*K*pad32(M) uint16 (K = contraction channels: Cin for fwd, Cout for dgrad; M the
  * other one), overwritten by the call; wsplit == NULL forces the fp32-MFMA kernels.  P2I_X6C_MIN_WG (read per call) overrides
- * the tile-count threshold (default 200 workgroups of 64 x 256 outputs). */
+ * the tile-count thresholds (default: 200 workgroups for a tile variant to be preferred, 64 for the smallest tile as the last resort). */
 int p2i_conv_fwd_x6(const p2i_conv_desc* d, const float* x, const float* wp, uint16_t* wsplit, const float* bias,
                     const float* residual, float* y, int act, void* stream);
 int p2i_conv_dgrad_x6(const p2i_conv_desc* d, const float* dy, const float* wp_d, uint16_t* wsplit, const float* dx_add,

@@ -1181,6 +1181,10 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
 // Fewest workgroups for which a tile variant is used (256 CUs; below that the next smaller tile, or the f32 engine).  Read per call
 // (not cached) so that the parity tests can send small layers through these kernels (P2I_X6C_MIN_WG=1).
 static int x6c_min_wg() { const char* e = getenv("P2I_X6C_MIN_WG"); return e ? atoi(e) : 200; }
+// When not even the smallest tile reaches that count, the smallest tile is still taken from this many workgroups on: a split-pipe
+// workgroup does its tile ~2x faster than the f32 engine's, which has no more workgroups to offer for the same layer (its smallest tile
+// is 32 x 128 too).  Small per-GPU batches live here: at B = 4 the 512-channel level has 128 tiles of 32 x 128.
+static int x6c_min_wg_low() { const char* e = getenv("P2I_X6C_MIN_WG"); if (e) return atoi(e); e = getenv("P2I_X6C_MIN_WG_LOW"); return e ? atoi(e) : 64; }
 static int x6c_pc();
 static int x6p_tn1() { const char* e = getenv("P2I_X6P_TN1"); return e ? atoi(e) : 1; }      // read per call (A/B runs)
 // the fused strided data gradient is taken from 128 workgroups on (half the chip, one round: the 128 -> 256 stride-2 layer at B = 8);
@@ -1212,6 +1216,7 @@ static X6cPick x6c_pick(int B, int nH, int nW, int Cm, int Ck, bool linear_epi, 
   // 73.5 us on the 256-channel level, inside the noise, not the default.)
   // (round 3: the 32 x 128 tile of the producer / consumer kernel comes before any split-K form; P2I_X6P_TN1=0 removes it)
   static const int order_a[5][2] = {{0, 0}, {1, 0}, {2, 0}, {1, 1}, {0, 1}}, order_b[5][2] = {{0, 0}, {0, 1}, {1, 0}, {2, 0}, {1, 1}};
+  X6cPick low{-1, 0, 0, 0, 0, 1, 0};                       // the un-split variant with the most workgroups below the threshold
   for (int cand = 0; cand < 5; ++cand) {
       const int v = (ksplit_on == 2 ? order_b : order_a)[cand][0], pass = (ksplit_on == 2 ? order_b : order_a)[cand][1];
       const X6cVariant& t = kX6cVariants[v];
@@ -1225,8 +1230,9 @@ static X6cPick x6c_pick(int B, int nH, int nW, int Cm, int Ck, bool linear_epi, 
       if (jt != 1 || csl > (t.NW == 8 ? X6cTile<8>::MAXCSL : X6cTile<4>::MAXCSL)) continue;
       const long long wgs = (long long)ceil_div(B, jb) * ceil_div(nH, jh) * ceil_div(nW, jw) * ceil_div(Cm, 32 * t.TM) * (pass + 1);
       if (wgs >= min_wg) return X6cPick{v, jb, jh, jw, csl, pass + 1, wgs};
+      if (pass == 0 && !forced && wgs >= x6c_min_wg_low() && (low.v < 0 || wgs > low.wgs)) low = X6cPick{v, jb, jh, jw, csl, 1, wgs};
     }
-  return X6cPick{-1, 0, 0, 0, 0, 1, 0};
+  return low;          // (v = -1 when nothing qualified: f32 engine)
 }
 
 // cheap host-side test used before the weights are split: would run_patch_gemm_x6c take this layer?

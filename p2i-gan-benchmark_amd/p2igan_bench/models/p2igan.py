@@ -325,8 +325,12 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False, on_l
     b, t, h, w = S["shape"]
     BASE_CH = net.base
     grads = {}
-    if inplace and any(p_.requires_grad and (p_.grad is None or not p_.grad.is_contiguous()) for p_ in net.parameters()):
-        raise RuntimeError("generator_backward(inplace=True) needs contiguous .grad views on every trainable parameter")
+    if inplace:
+        plist = getattr(net, "_plist", None)          # (Module.parameters() walks the tree: cached; parameters are never replaced)
+        if plist is None:
+            plist = net._plist = [p_ for p_ in net.parameters() if p_.requires_grad]
+        if any(p_.grad is None or not p_.grad.is_contiguous() for p_ in plist):
+            raise RuntimeError("generator_backward(inplace=True) needs contiguous .grad views on every trainable parameter")
     # in-place mode owns a persistent arena (nothing of it outlives this call); the autograd path hands arena views to
     # AccumulateGrad, which may keep them, so it gets a fresh one
     if inplace and (getattr(net, "_arena_buf", None) is None or net._arena_buf.numel() < net._arena_numel() or net._arena_buf.device != dout.device):

@@ -64,7 +64,7 @@ def _act_cpu(y, act):
 @pytest.fixture(params=["f32", "x6c", "x6c81", "x6c41", "x6c_sym"])
 def engine(request, ops, monkeypatch):
     """Both convolution engines are held to the same oracle: the f32-MFMA kernels and the bf16-split kernels (conv_x6c.hip: producer /
-    consumer kernels by default, "x6c_sym" = the symmetric ones).  The latter only take layers with >= 200 workgroups by default;
+    consumer kernels by default, "x6c_sym" = the symmetric ones).  The latter only take layers with >= 64 workgroups (200 for a variant to be preferred) by default;
     P2I_X6C_MIN_WG=1 (read per call) sends the small test layers they cover through them too, and P2I_X6C_TILE=<waves><channel tiles>
     pins one tile variant (default: 82 = 64 x 256 where it fills the chip, else 81 = 32 x 256, else 41 = 32 x 128 -- producer / consumer
     kernel only -- before any split-K launch)."""

@@ -9,7 +9,7 @@ from p2igan_bench.models import build_discriminator, build_generator
 from p2igan_bench.utils import seeded
 
 
-def run(B, H, W, T=16, steps=3, note=""):
+def run(B, H, W, T=16, steps=int(os.environ.get("SANITY_STEPS", "3")), note=""):
     cfg = {"seed": 1, "model": {"name": "p2igan", "in_channels": 1}, "data": {"train": {"h": H, "w": W, "sample_length": T}},
            "loss": {"use_gan": 1, "gan_loss": "hinge", "k1_weight": 0.05, "adversarial_weight": 0.01},
            "train": {"optimizer": {"lr": 1e-4, "beta1": 0.0, "beta2": 0.99}}}
