@@ -15,7 +15,8 @@
 //     taps 0-3, group 1 taps 5-8, the centre tap is shared (group 0 takes tile rows 0-1, group 1 rows 2-3, summed through LDS at
 //     the end): 108 MFMAs per wave and tile in both groups, five 32x32 accumulators per wave;
 //   * tile = 4 rows x 16 columns of output pixels (+ halo for x): both tiles go global -> registers -> split -> LDS as bf16 planes
-//     [plane][pixel][64 ch] with a 144-byte pixel pitch (writes conflict-free; transposed reads 2-way on 16 of 64 banks), double
+//     [plane][pixel][64 ch] with a 144-byte pixel pitch (writes conflict-free; transposed reads conflict-free since round 3: each read
+//     takes pixel rows r, r+4, r+8, r+12 -- wx_read_tr_s4), double
 //     buffered, ONE barrier per tile; no LDS-DMA (nothing here is consumed in its memory layout), so hipcc counts the waits;
 //   * a K-step is one tile row (16 pixels): 6 transposed reads for dy, 6 per tap for x, 24-30 MFMAs per wave; both tap groups run
 //     one static schedule of 18 tap-steps per tile with the operand reads two steps ahead and the next tile's staging (24 buffer
@@ -78,7 +79,18 @@ __device__ __forceinline__ bf16x8w wx_read_tr(const unsigned char* base, int byt
   const s16x4w b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + byte_off + 4 * WX_ROW));
   return __builtin_bit_cast(bf16x8w, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+// The same with the 16 pixel rows of a K-step dealt out so that no two lanes of a 32-lane half meet on a bank: the contraction index
+// of an MFMA has no order, only x and dy must agree on it.  A transposed read takes the four rows its lanes address (lane 4q+p: row
+// q of the block); with rows r0, r0+4, r0+8, r0+12 and the 144-byte pitch (36 dwords) the eight (row, 16-channel group) windows of a
+// half land on banks 16 q + 8 g .. + 7 -- all 64 banks once.  (Rows r0 .. r0+3, round 2: rows q and q+2 meet: 43 % of the LDS cycles
+// were conflict cycles.)  Half lhi reads rows 2 lhi + 4 q and, second read, one row further: every row of the K-step exactly once.
+__device__ __forceinline__ bf16x8w wx_read_tr_s4(const unsigned char* base, int byte_off) {
+  const s16x4w a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + byte_off));
+  const s16x4w b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + byte_off + WX_ROW));
+  return __builtin_bit_cast(bf16x8w, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 
+template <bool S4>
 __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,8 +186,9 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   // transposed-read lane bases (bytes inside a buffer): lane 4q+p of a 16-lane group addresses pixel row q, channels 4p .. 4p+3
-  const int a_lane = (8 * lhi + (i16 >> 2)) * WX_ROW + (32 * kh + 16 * g16 + 4 * (i16 & 3)) * 2;
-  const int b_lane = WX_YOFF + (8 * lhi + (i16 >> 2)) * WX_ROW + (32 * mh + 16 * g16 + 4 * (i16 & 3)) * 2;
+  const int lrow = S4 ? 2 * lhi + 4 * (i16 >> 2) : 8 * lhi + (i16 >> 2);                               // (rows: see wx_read_tr_s4)
+  const int a_lane = lrow * WX_ROW + (32 * kh + 16 * g16 + 4 * (i16 & 3)) * 2;
+  const int b_lane = WX_YOFF + lrow * WX_ROW + (32 * mh + 16 * g16 + 4 * (i16 & 3)) * 2;
   int a_tap[5];                                       // + the tap's pixel shift (dh, dw) -> dh * 18 + dw patch pixels; [4] = centre
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -222,12 +235,12 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
     auto load_a = [&](int set, int step) {
       const unsigned char* p = buf + a_tap[ST_K[step]] + rowx[ST_KS[step]];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) Av[set][pl] = wx_read_tr(p, pl * WX_XPLANE);
+      for (int pl = 0; pl < 3; ++pl) Av[set][pl] = S4 ? wx_read_tr_s4(p, pl * WX_XPLANE) : wx_read_tr(p, pl * WX_XPLANE);
     };
     auto load_b = [&](int set, int ks) {
       const unsigned char* p = buf + b_lane + rowy[ks];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) Bv[set][pl] = wx_read_tr(p, pl * WX_YPLANE);
+      for (int pl = 0; pl < 3; ++pl) Bv[set][pl] = S4 ? wx_read_tr_s4(p, pl * WX_YPLANE) : wx_read_tr(p, pl * WX_YPLANE);
     };
     // x operands are fetched TWO steps ahead (three register sets), dy operands at the first step of the K-step before
     load_b(0, 0);
@@ -528,7 +541,8 @@ int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float*
   g.pstride = slice;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)wgrad_x6p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -538,7 +552,12 @@ int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float*
   // an option (same results, tested); read per call.
   const char* pce = getenv("P2I_WGRAD_X6_PC");
   if (pce != nullptr && atoi(pce) != 0) hipLaunchKernelGGL(wgrad_x6p_kernel, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
-  else hipLaunchKernelGGL(wgrad_x6_kernel, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
+  // conflict-free row assignment of the transposed reads (wx_read_tr_s4): the default; P2I_WGRAD_X6_S4=0 keeps round 2's rows (A/B, read
+  // per call).  Measured in one box (gpurun_out/r03x/wg_s0.log, wg_s4.log, wg_s0b.log; PMC: gpurun_out/r03x/pmc): conflict cycles 43 % ->
+  // 0.5 % of the LDS cycles, launch time within 1 % (66.5-71.5 us either way): the transposed reads were never what the kernel waits for.
+  else if (!(getenv("P2I_WGRAD_X6_S4") && atoi(getenv("P2I_WGRAD_X6_S4")) == 0))
+    hipLaunchKernelGGL(wgrad_x6_kernel<true>, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
+  else hipLaunchKernelGGL(wgrad_x6_kernel<false>, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
   *ns_out = sliced ? ns : 0;
   *slice_out = slice;
   return launch_status();
