@@ -499,6 +499,37 @@ def test_autograd_step_matches_direct_step(dev):
     assert rel_err(db.cpu().numpy(), da.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("gan_type", ["hinge", "lsgan"])
+def test_overlapped_step_matches_serial_step(dev, monkeypatch, gan_type):
+    """The step's stream-level overlap (round 3: weight preparation, the real half of the D step incl. its backward, the
+    reconstruction loss and the generator's fold / unpack kernels on side streams) against the same step issued on ONE stream in the
+    reference's order: a step from the same state agrees to summation-order noise (the weight gradients of D's two halves are
+    added in the other order, atomically accumulated gradients have no order either way)."""
+    from p2igan_bench.engine import TrainEngine
+    from p2igan_bench.models import p2igan as net_fns
+    frames, masked, masks = [t.to(dev) for t in _batch32()]
+    res = []
+    for overlapped in (True, False):
+        cfg, G, D = _build(dev)
+        cfg = dict(cfg, loss=dict(cfg["loss"], gan_loss=gan_type))
+        monkeypatch.setattr(net_fns, "SIDE_WGRAD", overlapped)
+        monkeypatch.setattr(net_fns, "LATE_JOIN", overlapped)
+        eng = TrainEngine(G, D, cfg)
+        assert eng.direct and eng.prep_overlap
+        eng.prep_overlap = overlapped
+        r = eng.train_step(frames, masked, masks)
+        res.append(({k: float(r[k]) for k in ("loss_g", "loss_d", "rec", "adv", "pool", "reg")}, r["preds"].clone(),
+                    r["logits_real"].clone(), r["logits_fake"].clone(), eng.gp.grad.clone(), eng.dp.grad.clone()))
+        r2 = eng.train_step(frames, masked, masks)                 # (the side streams' buffers are reused: a second step must run clean)
+        assert all(bool(torch.isfinite(r2[k]).all()) for k in ("loss_g", "loss_d", "preds"))
+    (la, pa, ra, fa, ga, da), (lb, pb, rb, fb, gb, db) = res
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-5 * abs(la[k]) + 1e-9, (k, la[k], lb[k])
+    assert torch.equal(pa, pb) and torch.equal(ra, rb) and torch.equal(fa, fb)       # forwards run the same kernels on the same data
+    assert rel_err(gb.cpu().numpy(), ga.cpu().numpy()) < 1e-5
+    assert rel_err(db.cpu().numpy(), da.cpu().numpy()) < 1e-5
+
+
 def test_nsgan_matches_oracle_and_rejects_out_of_range(dev):
     """'nsgan' = nn.BCELoss on the raw logits (losses.py:201-202): runs only for logits in [0, 1] (torch raises otherwise)."""
     from oracle import p2i_oracle as orc
