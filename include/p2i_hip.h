@@ -16,8 +16,8 @@
  *    p2i_conv_*_x6 / p2i_conv_wgrad_ws call.  Tuning switches (P2I_* environment variables): the engine on/off switches
  *    (P2I_CONV_X6C, P2I_CONV_X6C_FUSED, P2I_X6C_KSPLIT, P2I_CONV_V4, P2I_CONV_CK16, P2I_CONV_KG27, P2I_DGRAD_FUSED, P2I_DGRAD_PAIR,
  *    P2I_C1_FAST, P2I_O1_FWD, P2I_WGRAD_X4, P2I_WGRAD_WINDOW) are read ONCE per process; the per-launch choices that the parity
- *    tests flip inside one process (P2I_X6C_MIN_WG, P2I_X6C_TILE, P2I_X6C_TPS, P2I_X6C_STAGGER, P2I_X6C_FUSED_KSPLIT, P2I_WGRAD_X6)
- *    are read on EVERY call;
+ *    tests flip inside one process (P2I_X6C_MIN_WG, P2I_X6C_MIN_WG_LOW, P2I_X6C_TILE, P2I_X6C_TPS, P2I_X6C_PC, P2I_X6P_NPW, P2I_X6P_TN1,
+ *    P2I_X6C_STAGGER, P2I_X6C_FUSED_KSPLIT, P2I_WGRAD_X6, P2I_WGRAD_X6_PC, P2I_WGRAD_X6_S4) are read on EVERY call;
  *  - aliasing: an output may alias the epilogue operand of the same call that is read element-for-element at the position it is
  *    written (y == residual, dx == dx_add, dx == mask_y): every kernel reads it before it writes that element, and the split-K
  *    launches of the bf16-split kernels (which zero-fill the destination first) are not chosen for an aliased call.  No other
