@@ -241,6 +241,11 @@ int p2i_pooldup_bwd(const float* x, const float* dy, float* dx, int B, int C, in
 
 /* UPPos front half (layer.py:392-396): u = bilinear_x2(x, align_corners=True) * 2*sigmoid(pos). */
 int p2i_upmod_fwd(const float* x, const float* pos, float* u, int B, int C, int S, int S2w /*in W*/, void* stream);
+/* The same with the rest of UPPos behind it: u = act(bilinear_x2(v) * 2*sigmoid(pos) + bias[c]).  The modulation is ONE factor per
+ * pixel for all channels and the upsampling acts on every channel alike, so the 1x1 projection (layer.py:390,397) commutes with
+ * both: relu(W (up(h) * s) + b) == relu(up(W h) * s + b).  The build projects at the LOW resolution (a quarter of the positions,
+ * v = W h through p2i_conv_fwd) and finishes here; equal to the reference's order up to fp32 rounding of the reordered sums. */
+int p2i_upmod_fwd_ba(const float* v, const float* pos, const float* bias, int act, float* u, int B, int C, int S, int S2w, void* stream);
 int p2i_upmod_bwd(const float* x, const float* pos, const float* du, float* dx, float* dpos,
                   int B, int C, int S, int S2w, void* stream);
 

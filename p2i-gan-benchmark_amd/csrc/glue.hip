@@ -199,8 +199,10 @@ __device__ __forceinline__ void ac_src(int o, float scale, int S, int& i0, int& 
 }
 // x (BC, Sh, Sw) -> u (BC, 2Sh, 2Sw); pos (2Sh, 2Sw).  Thread = one output pixel for a chunk of channels (blockIdx.y): the
 // bilinear taps and the modulation 1 + (2 sigmoid(pos) - 1) depend on the pixel only and are computed once, not per channel.
+// bias != null (round 3, UPPos with the 1x1 projection moved IN FRONT of the upsampling -- models/p2igan.py uppos): u = act(v (1 + pm)
+// + bias[channel]), C = channels per sample.
 __global__ __launch_bounds__(256) void upmod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos, float* u, int BC, int Sh, int Sw,
-                                                       int chunk) {
+                                                       int chunk, const float* __restrict__ bias, int act, int C) {
   const int Oh = 2 * Sh, Ow = 2 * Sw;
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= Oh * Ow) return;
@@ -217,7 +219,9 @@ __global__ __launch_bounds__(256) void upmod_fwd_kernel(const float* __restrict_
   for (int bc = bc0; bc < bc1; ++bc) {
     const float* px = x + bc * SS;
     const float v = (1.f - ly) * ((1.f - lx) * px[i00] + lx * px[i01]) + ly * ((1.f - lx) * px[i10] + lx * px[i11]);
-    u[bc * OO + pix] = v + v * pm;
+    float r = v + v * pm;
+    if (bias) r = act_apply(r + bias[bc % C], act);
+    u[bc * OO + pix] = r;
   }
 }
 // dpos[y,x] += sum_{bc in chunk} du * v * 2 s (1-s);   grid.y = bc chunks
@@ -482,8 +486,18 @@ extern "C" int p2i_upmod_fwd(const float* x, const float* pos, float* u, int B, 
     const int BC = B * C, npix = 4 * S * S2w;
     int chunk = BC;                                  // enough (pixel tile, channel chunk) blocks to fill the chip ~8 times
     while (chunk > 8 && (long long)ceil_div(npix, 256) * ceil_div(BC, chunk) < 2048) chunk = (chunk + 1) / 2;
-    hipLaunchKernelGGL(upmod_fwd_kernel, dim3(ceil_div(npix, 256), ceil_div(BC, chunk)), dim3(256), 0, (hipStream_t)stream, x, pos, u, BC, S, S2w, chunk);
+    hipLaunchKernelGGL(upmod_fwd_kernel, dim3(ceil_div(npix, 256), ceil_div(BC, chunk)), dim3(256), 0, (hipStream_t)stream, x, pos, u, BC, S, S2w, chunk,
+                       (const float*)nullptr, P2I_ACT_NONE, C);
   }
+  return launch_status();
+}
+extern "C" int p2i_upmod_fwd_ba(const float* x, const float* pos, const float* bias, int act, float* u, int B, int C, int S, int S2w, void* stream) {
+  P2I_REQUIRE(x && pos && bias && u, "null pointer");
+  const int BC = B * C, npix = 4 * S * S2w;
+  int chunk = BC;
+  while (chunk > 8 && (long long)ceil_div(npix, 256) * ceil_div(BC, chunk) < 2048) chunk = (chunk + 1) / 2;
+  hipLaunchKernelGGL(upmod_fwd_kernel, dim3(ceil_div(npix, 256), ceil_div(BC, chunk)), dim3(256), 0, (hipStream_t)stream, x, pos, u, BC, S, S2w, chunk,
+                     bias, act, C);
   return launch_status();
 }
 extern "C" int p2i_upmod_bwd(const float* x, const float* pos, const float* du, float* dx, float* dpos, int B, int C, int S,

@@ -287,13 +287,17 @@ def generator_forward(net: "P2IGenerator", masked_frames, masks, need_grad: bool
         return hcur, rec
 
     def uppos(i, hcur):
+        # UPPos (layer.py:384-399): relu(W (up(h) * s) + b) with s = 2 sigmoid(pos) ONE factor per pixel.  The projection acts on
+        # channels, the upsampling and s on positions, alike for every channel: they commute, relu(up(W h) * s + b) is the same
+        # function -- projected at the LOW resolution (a quarter of the GEMM's positions, and the upsampling runs on C/2 channels),
+        # finished by one bandwidth kernel.  Equal to the reference's order to fp32 rounding of the reordered sums.
         up = net.UP[i]
         cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
-        u = ops.upmod_fwd(hcur, up.pos)
         pack = lambda: ops.weight_pack(up.proj.weight.reshape(cout_, cin_, 1), need_d=need_grad)
         wp = prep["up"][i] if prep is not None else (pack() if need_grad else net._cached(id(up), (up.proj.weight,), pack))
-        r = ops.conv_fwd(_spec2d(cin_, cout_, 1), u, wp[0], bias=up.proj.bias, act=ACT_RELU)
-        return r, (hcur, u, r, wp[1])
+        v = ops.conv_fwd(_spec2d(cin_, cout_, 1), hcur, wp[0])
+        r = ops.upmod_fwd(v, up.pos, bias=up.proj.bias, act=ACT_RELU)
+        return r, (hcur, v, r, wp[1])
 
     h3, rec3 = eblock(3, x_8)
     res1, up2 = uppos(2, h3)
@@ -396,14 +400,16 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False, on_l
 
     def uppos_bwd(i, dr):
         up = net.UP[i]
-        hin, u, r, wpd = S["up"][i]
+        hin, v, r, wpd = S["up"][i]
         cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
         spec = _spec2d(cin_, cout_, 1)
-        dr = ops.act_bwd(dr, r, ACT_RELU)                       # * relu'(r) once, for wgrad and dgrad
-        dwp, db = wgrad(spec, u, dr, want_bias=True, db_out=_grad_target(up.proj.bias, inplace))
+        dz = ops.act_bwd(dr, r, ACT_RELU)                       # * relu'(r)
+        db = ops.bias_grad(dz, out=_grad_target(up.proj.bias, inplace))
+        # through the modulation and the upsampling, down to the low resolution: d v, and d pos = sum_c dz * up(v) * s'
+        dv, dpos = ops.upmod_bwd(v, up.pos, dz, dpos_out=_grad_target(up.pos, inplace))
+        dwp, _ = wgrad(spec, hin, dv)
         gw_ = weight_side(lambda: ops.weight_unpack_grad(dwp, up.proj.weight.reshape(cout_, cin_, 1), out=_grad_target(up.proj.weight, inplace)))
-        du = ops.conv_dgrad(spec, dr, wpd, tuple(u.shape))
-        dx, dpos = ops.upmod_bwd(hin, up.pos, du, dpos_out=_grad_target(up.pos, inplace))
+        dx = ops.conv_dgrad(spec, dv, wpd, tuple(hin.shape))
         if not inplace:
             grads[id(up.proj.weight)] = gw_.reshape(up.proj.weight.shape)
             grads[id(up.proj.bias)] = db

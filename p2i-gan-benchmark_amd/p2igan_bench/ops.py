@@ -807,14 +807,21 @@ def pooldup_bwd(x, dy):
     return dx
 
 
-def upmod_fwd(x, pos):
+def upmod_fwd(x, pos, bias=None, act=ACT_NONE):
+    """bilinear x2 (align_corners) * 2 sigmoid(pos); with `bias`: act(that + bias[c]) -- UPPos's tail when the 1x1 projection has
+    already been applied at the low resolution (p2i_upmod_fwd_ba in p2i_hip.h has the algebra)."""
     lib = _hip.load()
     B, Cc, Sh, Sw = x.shape
     if pos.numel() != 4 * Sh * Sw:
         raise RuntimeError(f"upmod_fwd: pos has {pos.numel()} elements, expected {4 * Sh * Sw}")
     u = torch.empty((B, Cc, 2 * Sh, 2 * Sw), device=x.device, dtype=torch.float32)
-    _chk(x, pos)
-    _hip.check(lib.p2i_upmod_fwd(_ptr(x), _ptr(pos), _ptr(u), B, Cc, Sh, Sw, _stream()), "p2i_upmod_fwd")
+    _chk(x, pos, bias)
+    if bias is not None:
+        if bias.numel() != Cc:
+            raise RuntimeError("upmod_fwd: bias size mismatch")
+        _hip.check(lib.p2i_upmod_fwd_ba(_ptr(x), _ptr(pos), _ptr(bias), act, _ptr(u), B, Cc, Sh, Sw, _stream()), "p2i_upmod_fwd_ba")
+    else:
+        _hip.check(lib.p2i_upmod_fwd(_ptr(x), _ptr(pos), _ptr(u), B, Cc, Sh, Sw, _stream()), "p2i_upmod_fwd")
     return u
 
 
@@ -975,11 +982,14 @@ def act_bwd(dy, y, act):
     return out
 
 
-def bias_grad(dy, y_act=None, act=ACT_NONE):
+def bias_grad(dy, y_act=None, act=ACT_NONE, out=None):
+    """out: caller-owned ZEROED (Cc,) target the kernel adds into."""
     lib = _hip.load()
     B, Cc = dy.shape[0], dy.shape[1]
     inner = dy[0, 0].numel()
-    db = zero_(torch.empty(Cc, device=dy.device, dtype=torch.float32))
+    if out is not None and out.numel() != Cc:
+        raise RuntimeError("bias_grad: target size mismatch")
+    db = out if out is not None else zero_(torch.empty(Cc, device=dy.device, dtype=torch.float32))
     _chk(dy, y_act)
     _hip.check(lib.p2i_bias_grad(_ptr(dy), _ptr(y_act), act, _ptr(db), B, Cc, inner, _stream()), "p2i_bias_grad")
     return db

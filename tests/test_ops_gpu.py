@@ -422,6 +422,40 @@ def test_upmod(ops, S):
     assert rel_err(dpos.cpu().numpy(), pos.grad.numpy()) < TOL_WGRAD
 
 
+@pytest.mark.parametrize("cin,cout,S", [(64, 32, 8), (128, 64, 16), (32, 16, 4)])
+def test_uppos_projection_at_low_resolution_equals_reference_order(ops, cin, cout, S):
+    """UPPos (layer.py:384-399) in the reference's order -- upsample, modulate, 1x1 conv + bias, ReLU -- against the build's order:
+    1x1 conv at the LOW resolution, then upsample * modulation + bias, ReLU in one kernel (the projection commutes with the two
+    per-pixel operators); forward and every gradient (input, weight, bias, pos) through the same op sequence the model code runs."""
+    x = _rand(2, cin, S, S, seed=1).requires_grad_(True)
+    pos = _rand(1, 1, 2 * S, 2 * S, seed=2, scale=0.5).requires_grad_(True)
+    w = _rand(cout, cin, 1, 1, seed=3, scale=1.0 / np.sqrt(cin)).requires_grad_(True)
+    b = _rand(cout, seed=4, scale=0.1).requires_grad_(True)
+    u = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    u = u + u * (2 * torch.sigmoid(pos) - 1)
+    r = F.relu(F.conv2d(u, w, b))
+    gout = _rand(*r.shape, seed=5)
+    r.backward(gout)
+
+    dev = "cuda"
+    spec = ops.ConvSpec(cin, cout, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    wp_f, wp_d = ops.weight_pack(w.detach().reshape(cout, cin, 1).to(dev))
+    xg, pg, bg = x.detach().to(dev), pos.detach().to(dev), b.detach().to(dev)
+    v = ops.conv_fwd(spec, xg, wp_f)
+    rg = ops.upmod_fwd(v, pg, bias=bg, act=ops.ACT_RELU)
+    assert rel_err(rg.cpu().numpy(), r.detach().numpy()) < TOL_OP
+    dz = ops.act_bwd(gout.to(dev), rg, ops.ACT_RELU)
+    db = ops.bias_grad(dz)
+    dv, dpos = ops.upmod_bwd(v, pg, dz)
+    dwp, _ = ops.conv_wgrad(spec, xg, dv)
+    dw = ops.weight_unpack_grad(dwp, w.detach().reshape(cout, cin, 1).to(dev))
+    dx = ops.conv_dgrad(spec, dv, wp_d, tuple(x.shape))
+    assert rel_err(dx.cpu().numpy(), x.grad.numpy()) < TOL_OP
+    assert rel_err(dw.cpu().numpy().reshape(w.shape), w.grad.numpy()) < TOL_WGRAD
+    assert rel_err(db.cpu().numpy(), b.grad.numpy()) < TOL_WGRAD
+    assert rel_err(dpos.cpu().numpy(), pos.grad.numpy()) < TOL_WGRAD
+
+
 @pytest.mark.parametrize("dims", [(8, 8, 2, 4, 4), (32, 32, 8, 16, 16), (8, 8, 4, 8, 8)])
 def test_dtail(ops, dims):
     H2, W2, T3, H3, W3 = dims

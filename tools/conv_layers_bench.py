@@ -21,9 +21,9 @@ LAYERS = [("G l0 3x3 64", S2(64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)), (64, 1, 1
           ("G l2 3x3 256", S2(256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1)), (256, 1, 32, 32)),
           ("G l3 3x3 512", S2(512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1)), (512, 1, 16, 16)),
           ("G in 16->64 g4", S2(16, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)), (16, 1, 128, 128)),
-          ("G up 512->256 1x1", S2(512, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)), (512, 1, 32, 32)),
-          ("G up 256->128 1x1", S2(256, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)), (256, 1, 64, 64)),
-          ("G up 128->64 1x1", S2(128, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)), (128, 1, 128, 128)),
+          ("G up 512->256 1x1", S2(512, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)), (512, 1, 16, 16)),      # (round 3: projected at the LOW
+          ("G up 256->128 1x1", S2(256, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)), (256, 1, 32, 32)),      # resolution, in front of the
+          ("G up 128->64 1x1", S2(128, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)), (128, 1, 64, 64)),        # upsampling)
           ("G out 64->16 1x1", S2(64, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0)), (64, 1, 128, 128)),
           ("D2 16->64 s1", S2(16, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)), (16, 1, 128, 128)),
           ("D2 64->128 s2", S2(64, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)), (64, 1, 128, 128)),
