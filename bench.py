@@ -480,6 +480,7 @@ def main():
         threads = int(os.environ.get("P2I_CPU_THREADS", phys))
         cpu = cpu_baseline(args.cpu_batch, args.cpu_steps, threads)
         cpu["cores_available"] = avail
+        cpu["cores_note"] = "cores = the threads used = every core this process may run on (the lease's share of the host, not the whole socket)"
 
     if rank == 0:
         line = {"metric": "train frames/sec (128x128x16)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,

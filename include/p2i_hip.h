@@ -283,6 +283,15 @@ int p2i_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
 int p2i_assemble_batch(const uint8_t* frames_u8, const uint8_t* mask_u8, int64_t mask_numel, float* frames,
                        float* masked, float* masks, int B, int T, int H, int W, void* stream);
 
+/* ------------------------------------------------------------------ sliding-window inference (infer.py:188-262)
+ * Window w of an event (L frames of HW floats) = frames w*step .. w*step+win-1, frames past the end repeat the last one
+ * (infer.py:219-227).  p2i_window_gather builds windows w0 .. w0+nw-1 of up to two tensors (masked frames and masks) as
+ * (nw, win, HW); p2i_window_mean turns the generator's predictions for ALL nwin windows, (nwin, win, HW), into the event:
+ * out[l] = max(0, scale * mean over the windows that hold frame l) (the repeated copies are not counted, infer.py:229-245). */
+int p2i_window_gather(const float* a, const float* b /*may be NULL*/, float* wa, float* wb, int L, int64_t HW, int w0, int nw, int win,
+                      int step, void* stream);
+int p2i_window_mean(const float* pred_windows, float* out, int L, int64_t HW, int nwin, int win, int step, float scale, void* stream);
+
 /* ------------------------------------------------------------------ evaluation metrics
  * metrics/metric.py on the device.  p2i_metrics_pointwise (one pass over pred/target, n elements): sums2[0] += sum|d|,
  * sums2[1] += sum d^2 with d = T(pred) - T(target), T(x) = 10^(x/16)*0.036 when apply_transform (RegressionMetrics.update

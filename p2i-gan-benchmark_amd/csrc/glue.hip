@@ -613,6 +613,57 @@ __global__ __launch_bounds__(256) void assemble_batch_kernel(const uint8_t* __re
 }
 }  // namespace p2i
 
+// ---- sliding-window inference (infer.py:188-262): window w = frames w*step .. w*step + win - 1 of an (L, HW) event, frames past the
+// end repeat the last one; the prediction of frame l is the mean over the windows that hold it (not counting the repeated copies),
+// scaled and clipped at 0.
+__global__ __launch_bounds__(256) void window_gather_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ wa,
+                                                           float* __restrict__ wb, int L, int64_t HW4, int w0, int nw, int win, int step) {
+  const int64_t per = (int64_t)win * HW4;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < (int64_t)nw * per; i += (int64_t)gridDim.x * 256) {
+    const int w = (int)(i / per);
+    const int64_t r = i - (int64_t)w * per;
+    const int k = (int)(r / HW4);
+    const int64_t p = r - (int64_t)k * HW4;
+    const int l = min((w0 + w) * step + k, L - 1);
+    reinterpret_cast<float4*>(wa)[i] = reinterpret_cast<const float4*>(a)[(int64_t)l * HW4 + p];
+    if (b) reinterpret_cast<float4*>(wb)[i] = reinterpret_cast<const float4*>(b)[(int64_t)l * HW4 + p];
+  }
+}
+__global__ __launch_bounds__(256) void window_mean_kernel(const float* __restrict__ pw, float* __restrict__ out, int L, int64_t HW4, int nwin, int win,
+                                                         int step, float scale) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < (int64_t)L * HW4; i += (int64_t)gridDim.x * 256) {
+    const int l = (int)(i / HW4);
+    const int64_t p = i - (int64_t)l * HW4;
+    // windows w with 0 <= l - w*step < win, in window order (the reference accumulates them in that order)
+    const int wlo = l - win + 1 > 0 ? (l - win + 1 + step - 1) / step : 0, whi = min(l / step, nwin - 1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = wlo; w <= whi; ++w) {
+      const float4 v = reinterpret_cast<const float4*>(pw)[((int64_t)w * win + (l - w * step)) * HW4 + p];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float c = fmaxf((float)(whi - wlo + 1), 1e-5f);
+    acc.x = fmaxf(acc.x / c * scale, 0.f); acc.y = fmaxf(acc.y / c * scale, 0.f);
+    acc.z = fmaxf(acc.z / c * scale, 0.f); acc.w = fmaxf(acc.w / c * scale, 0.f);
+    reinterpret_cast<float4*>(out)[i] = acc;
+  }
+}
+extern "C" int p2i_window_gather(const float* a, const float* b, float* wa, float* wb, int L, int64_t HW, int w0, int nw, int win, int step,
+                                 void* stream) {
+  P2I_REQUIRE(a && wa && (b == nullptr) == (wb == nullptr), "null pointer");
+  P2I_REQUIRE(L > 0 && nw > 0 && win > 0 && step > 0 && HW > 0 && (HW & 3) == 0, "bad window geometry (H*W must be a multiple of 4)");
+  P2I_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)wa | (uintptr_t)wb) & 15) == 0, "16-byte alignment");
+  hipLaunchKernelGGL(window_gather_kernel, dim3(grid_for((int64_t)nw * win * (HW / 4))), dim3(256), 0, (hipStream_t)stream, a, b, wa, wb, L, HW / 4,
+                     w0, nw, win, step);
+  return launch_status();
+}
+extern "C" int p2i_window_mean(const float* pred_windows, float* out, int L, int64_t HW, int nwin, int win, int step, float scale, void* stream) {
+  P2I_REQUIRE(pred_windows && out, "null pointer");
+  P2I_REQUIRE(L > 0 && nwin > 0 && win > 0 && step > 0 && HW > 0 && (HW & 3) == 0 && (nwin - 1) * step < L, "bad window geometry");
+  P2I_REQUIRE((((uintptr_t)pred_windows | (uintptr_t)out) & 15) == 0, "16-byte alignment");
+  hipLaunchKernelGGL(window_mean_kernel, dim3(grid_for((int64_t)L * (HW / 4))), dim3(256), 0, (hipStream_t)stream, pred_windows, out, L, HW / 4, nwin,
+                     win, step, scale);
+  return launch_status();
+}
 extern "C" int p2i_assemble_batch(const uint8_t* frames_u8, const uint8_t* mask_u8, int64_t mask_numel, float* frames,
                                   float* masked, float* masks, int B, int T, int H, int W, void* stream) {
   P2I_REQUIRE(frames_u8 && mask_u8 && frames && masked && masks, "null pointer");

@@ -60,6 +60,8 @@ SIGNATURES = {
     "p2i_pooldup_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "p2i_pooldup_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "p2i_upmod_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "p2i_window_gather": [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P],
+    "p2i_window_mean": [_P, _P, _I, _L, _I, _I, _I, _F, _P],
     "p2i_upmod_fwd_ba": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "p2i_upmod_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "p2i_dtail_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -10,9 +10,23 @@ import torch
 @torch.no_grad()
 def infer_event(generator, masked: torch.Tensor, masks: torch.Tensor, stride: int = 16, overlap: int = 12,
                 output_scale: float = 255.0, max_windows_per_batch: int = 32) -> torch.Tensor:
-    """masked, masks: (1, L, 1, H, W) on the generator's device -> (L, 1, H, W) float32."""
+    """masked, masks: (1, L, 1, H, W) on the generator's device -> (L, 1, H, W) float32.
+    HIP tensors (H*W a multiple of 4): windows are gathered and the overlap average / scale / clip is taken by two bandwidth kernels
+    (p2i_window_gather, p2i_window_mean) -- no index tensors, no boolean-mask indexing (a device-to-host sync in ATen).  CPU tensors
+    (drop-in users, tests): the same arithmetic in torch."""
     L = masked.shape[1]
     step = max(1, stride - overlap)
+    nwin = len(range(0, L, step))
+    hw = masked.shape[-2] * masked.shape[-1]
+    if masked.is_cuda and hw % 4 == 0:
+        from . import ops
+        m0, k0 = masked[0].contiguous().float(), masks[0].contiguous().float()
+        preds = torch.empty((nwin, stride) + tuple(masked.shape[2:]), device=masked.device, dtype=torch.float32)
+        for s in range(0, nwin, max_windows_per_batch):
+            nw = min(max_windows_per_batch, nwin - s)
+            wm, wk = ops.window_gather(m0, k0, L, s, nw, stride, step)
+            preds[s:s + nw] = generator(wm, wk)                  # (nw, stride, 1, H, W)
+        return ops.window_mean(preds, L, stride, step, output_scale)
     starts = list(range(0, L, step))
     idx = torch.arange(stride, device=masked.device).unsqueeze(0) + torch.tensor(starts, device=masked.device).unsqueeze(1)
     valid = idx < L                                             # (nwin, stride)

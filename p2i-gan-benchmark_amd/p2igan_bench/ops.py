@@ -995,6 +995,30 @@ def bias_grad(dy, y_act=None, act=ACT_NONE, out=None):
     return db
 
 
+# --------------------------------------------------------------------------- sliding-window inference
+def window_gather(a, b, L, w0, nw, win, step):
+    """Windows w0 .. w0+nw-1 (win frames every `step`, the last frame repeated past the end) of the (L, ...) tensors a and b
+    (b may be None) as (nw, win, ...) tensors."""
+    lib = _hip.load()
+    hw = a[0].numel()
+    wa = torch.empty((nw, win) + tuple(a.shape[1:]), device=a.device, dtype=torch.float32)
+    wb = torch.empty_like(wa) if b is not None else None
+    _chk(a, b)
+    _hip.check(lib.p2i_window_gather(_ptr(a), _ptr(b), _ptr(wa), _ptr(wb), L, hw, w0, nw, win, step, _stream()), "p2i_window_gather")
+    return wa, wb
+
+
+def window_mean(pred_windows, L, win, step, scale):
+    """(nwin, win, ...) predictions of all windows of an event -> (L, ...): mean over the windows that hold each frame, * scale, >= 0."""
+    lib = _hip.load()
+    nwin = pred_windows.shape[0]
+    hw = pred_windows[0, 0].numel()
+    out = torch.empty((L,) + tuple(pred_windows.shape[2:]), device=pred_windows.device, dtype=torch.float32)
+    _chk(pred_windows)
+    _hip.check(lib.p2i_window_mean(_ptr(pred_windows), _ptr(out), L, hw, nwin, win, step, float(scale), _stream()), "p2i_window_mean")
+    return out
+
+
 # --------------------------------------------------------------------------- batch assembly
 def assemble_batch(frames_u8, mask_u8):
     """uint8 frames (B,T,H,W) + uint8 mask (H,W) | (T,H,W) | (B,T,H,W) -> (frames, masked, masks), each (B,T,1,H,W) fp32:

@@ -456,6 +456,25 @@ def test_uppos_projection_at_low_resolution_equals_reference_order(ops, cin, cou
     assert rel_err(dpos.cpu().numpy(), pos.grad.numpy()) < TOL_WGRAD
 
 
+@pytest.mark.parametrize("L,win,step,batch", [(40, 16, 4, 32), (21, 16, 4, 3), (7, 16, 4, 32), (16, 16, 4, 2), (33, 8, 8, 32), (19, 16, 1, 5)])
+def test_sliding_window_inference_kernels_match_torch(ops, L, win, step, batch):
+    """p2i_window_gather / p2i_window_mean (the HIP path of inference.infer_event) against the torch formulation of infer.py:188-262
+    (index tensors, index_add_, the last frame repeated, repeated copies not counted), with a stand-in generator; ragged ends, events
+    shorter than a window, several batches of windows."""
+    from p2igan_bench.inference import infer_event
+    H = W = 8
+    masked, masks = _rand(1, L, 1, H, W, seed=1).abs(), (_rand(1, L, 1, H, W, seed=2) > 0).float()
+    gen = lambda a, b: a * 0.5 + b * 0.25 + (a * b).roll(1, dims=1) - 0.3            # mixes frames of a window: position in the window matters
+    ref = infer_event(gen, masked, masks, stride=win, overlap=win - step, output_scale=255.0, max_windows_per_batch=batch)      # CPU: torch path
+    got = infer_event(gen, masked.cuda(), masks.cuda(), stride=win, overlap=win - step, output_scale=255.0, max_windows_per_batch=batch)
+    assert got.shape == ref.shape
+    assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-6
+    nwin = len(range(0, L, step))
+    wa, wb = ops.window_gather(masked[0].cuda(), masks[0].cuda(), L, 0, nwin, win, step)
+    idx = (torch.arange(win).unsqueeze(0) + torch.arange(0, L, step).unsqueeze(1)).clamp(max=L - 1)
+    assert torch.equal(wa.cpu(), masked[0][idx]) and torch.equal(wb.cpu(), masks[0][idx])
+
+
 @pytest.mark.parametrize("dims", [(8, 8, 2, 4, 4), (32, 32, 8, 16, 16), (8, 8, 4, 8, 8)])
 def test_dtail(ops, dims):
     H2, W2, T3, H3, W3 = dims
