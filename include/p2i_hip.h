@@ -318,6 +318,8 @@ int p2i_zero(float* p, int64_t n, void* stream);                                
 /* out = dy * act'(y) for a saved post-activation tensor y (may alias dy): ReLU / LeakyReLU(0.2) / tanh backward */
 int p2i_act_bwd(const float* dy, const float* y, int act, float* out, int64_t n, void* stream);
 int p2i_bias_grad(const float* dy, const float* y_act, int act, float* db, int B, int C, int64_t inner, void* stream);
+/* both in one pass: out = dy * act'(y) and db[c] += its sum over samples and positions (db zeroed by the caller; inner % 4 == 0) */
+int p2i_act_bwd_bias(const float* dy, const float* y, int act, float* out, float* db, int B, int C, int64_t inner, void* stream);
 
 #ifdef __cplusplus
 }

@@ -379,6 +379,25 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, const float* __re
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) atomicAdd(db + c, acc);
 }
+// out = dy * act'(y) AND db[c] += sum of it, one pass (UPPos backward: the masked gradient feeds the upsampling's adjoint, its channel
+// sums are the bias gradient).  Block = (channel c, sample b, chunk of the plane); float4 streams, inner % 4 == 0.
+__global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, float* __restrict__ out,
+                                                          float* db, int C, int64_t inner4) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int64_t base = ((int64_t)b * C + c) * inner4;
+  const int64_t per = (inner4 + gridDim.z - 1) / gridDim.z;
+  const int64_t lo = per * blockIdx.z, hi = lo + per < inner4 ? lo + per : inner4;
+  float acc = 0.f;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const float4 g = reinterpret_cast<const float4*>(dy)[base + i], v = reinterpret_cast<const float4*>(y)[base + i];
+    const float4 r = make_float4(act_grad(g.x, v.x, act), act_grad(g.y, v.y, act), act_grad(g.z, v.z, act), act_grad(g.w, v.w, act));
+    reinterpret_cast<float4*>(out)[base + i] = r;
+    acc += (r.x + r.y) + (r.z + r.w);
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(db + c, acc);
+}
 // out = dy * act'(y) (y = saved post-activation tensor); float4 streams
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, float* out, int64_t n4, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -549,6 +568,14 @@ extern "C" int p2i_bias_grad(const float* dy, const float* y_act, int act, float
 extern "C" int p2i_act_bwd(const float* dy, const float* y, int act, float* out, int64_t n, void* stream) {
   P2I_REQUIRE(dy && y && out && n > 0, "null pointer");
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dy, y, act, out, n / 4, n);
+  return launch_status();
+}
+extern "C" int p2i_act_bwd_bias(const float* dy, const float* y, int act, float* out, float* db, int B, int C, int64_t inner, void* stream) {
+  P2I_REQUIRE(dy && y && out && db && B > 0 && C > 0 && inner > 0, "null pointer");
+  P2I_REQUIRE((inner & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) & 15) == 0, "inner % 4 and 16-byte alignment");
+  int chunks = (int)((inner / 4 + 2047) / 2048);
+  if (chunks > 16) chunks = 16;
+  hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(C, B, chunks), dim3(256), 0, (hipStream_t)stream, dy, y, act, out, db, C, inner / 4);
   return launch_status();
 }
 extern "C" int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stream) {

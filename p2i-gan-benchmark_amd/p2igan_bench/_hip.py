@@ -78,6 +78,7 @@ SIGNATURES = {
     "p2i_zero": [_P, _L, _P],
     "p2i_act_bwd": [_P, _P, _I, _P, _L, _P],
     "p2i_bias_grad": [_P, _P, _I, _P, _I, _I, _L, _P],
+    "p2i_act_bwd_bias": [_P, _P, _I, _P, _P, _I, _I, _L, _P],
 }
 
 

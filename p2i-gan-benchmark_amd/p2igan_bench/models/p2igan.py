@@ -403,8 +403,7 @@ def generator_backward(net: "P2IGenerator", S, dout, inplace: bool = False, on_l
         hin, v, r, wpd = S["up"][i]
         cin_, cout_ = up.proj.weight.shape[1], up.proj.weight.shape[0]
         spec = _spec2d(cin_, cout_, 1)
-        dz = ops.act_bwd(dr, r, ACT_RELU)                       # * relu'(r)
-        db = ops.bias_grad(dz, out=_grad_target(up.proj.bias, inplace))
+        dz, db = ops.act_bwd_bias(dr, r, ACT_RELU, db_out=_grad_target(up.proj.bias, inplace))      # * relu'(r), and its channel sums
         # through the modulation and the upsampling, down to the low resolution: d v, and d pos = sum_c dz * up(v) * s'
         dv, dpos = ops.upmod_bwd(v, up.pos, dz, dpos_out=_grad_target(up.pos, inplace))
         dwp, _ = wgrad(spec, hin, dv)

@@ -982,6 +982,21 @@ def act_bwd(dy, y, act):
     return out
 
 
+def act_bwd_bias(dy, y, act, db_out=None):
+    """(dy * act'(y), its per-channel sum) in one pass; db_out: caller-owned ZEROED (C,) target the kernel adds into."""
+    lib = _hip.load()
+    B, Cc = dy.shape[0], dy.shape[1]
+    inner = dy[0, 0].numel()
+    if inner % 4:
+        dz = act_bwd(dy, y, act)
+        return dz, bias_grad(dz, out=db_out)
+    out = torch.empty_like(dy)
+    db = db_out if db_out is not None else zero_(torch.empty(Cc, device=dy.device, dtype=torch.float32))
+    _chk(dy, y, db)
+    _hip.check(lib.p2i_act_bwd_bias(_ptr(dy), _ptr(y), act, _ptr(out), _ptr(db), B, Cc, inner, _stream()), "p2i_act_bwd_bias")
+    return out, db
+
+
 def bias_grad(dy, y_act=None, act=ACT_NONE, out=None):
     """out: caller-owned ZEROED (Cc,) target the kernel adds into."""
     lib = _hip.load()

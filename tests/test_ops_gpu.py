@@ -444,8 +444,8 @@ def test_uppos_projection_at_low_resolution_equals_reference_order(ops, cin, cou
     v = ops.conv_fwd(spec, xg, wp_f)
     rg = ops.upmod_fwd(v, pg, bias=bg, act=ops.ACT_RELU)
     assert rel_err(rg.cpu().numpy(), r.detach().numpy()) < TOL_OP
-    dz = ops.act_bwd(gout.to(dev), rg, ops.ACT_RELU)
-    db = ops.bias_grad(dz)
+    dz, db = ops.act_bwd_bias(gout.to(dev), rg, ops.ACT_RELU)
+    assert torch.equal(dz, ops.act_bwd(gout.to(dev), rg, ops.ACT_RELU))
     dv, dpos = ops.upmod_bwd(v, pg, dz)
     dwp, _ = ops.conv_wgrad(spec, xg, dv)
     dw = ops.weight_unpack_grad(dwp, w.detach().reshape(cout, cin, 1).to(dev))
