@@ -290,8 +290,8 @@ def infer_leg(dev, length=40, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)         # (0.6 s of timed steps; 20 / 5 until the end of round 3: the first timed
+    ap.add_argument("--warmup", type=int, default=10)        #  steps of a cold process ran 2-3 % slower than the steady state)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (configs[1]: 8)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-batch", type=int, default=8)
