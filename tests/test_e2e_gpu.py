@@ -93,6 +93,29 @@ def test_train_steps_match_reference_golden(dev, golden):
     assert rel_err(D.state_dict()["d2d.2.bias"].cpu().numpy(), g["d3/d2d.2.bias"]) < 1e-3
 
 
+def test_generator_only_training_step_matches_oracle(dev):
+    """The reference's non-GAN config (p2igan_baseline.json: use_gan 0): reconstruction loss only, no discriminator.  The engine's
+    side-stream preparation must work without a D step; predictions, loss and every generator gradient against the oracle."""
+    from oracle import p2i_oracle as orc
+    from p2igan_bench.engine import TrainEngine
+    from p2igan_bench.utils import seeded
+    cfg, G, _ = _build(dev)
+    cfg = dict(cfg, loss=dict(cfg["loss"], use_gan=0))
+    eng = TrainEngine(G, None, cfg)
+    assert not eng.use_gan and eng.prep_overlap
+    frames, masked, masks = _batch32()
+    r = eng.train_step(frames.to(dev), masked.to(dev), masks.to(dev))
+    ref = orc.TrainState(seeded.seeded_generator_state(32, 32), None, cfg["loss"], cfg["train"]["optimizer"]).step(frames, masked, masks, keep_grads=True)
+    assert rel_err(r["preds"].cpu().numpy(), ref["preds"].numpy()) < TOL
+    assert abs(float(r["loss_g"]) - ref["loss_g"]) <= TOL * abs(ref["loss_g"])
+    gparams = dict(G.named_parameters())
+    for n, gr in ref["ggrads"].items():
+        if gr is not None:
+            assert abs(float(gparams[n].grad.norm()) - float(gr.norm())) <= 1e-3 * float(gr.norm()) + 1e-7, n
+    r2 = eng.train_step(frames.to(dev), masked.to(dev), masks.to(dev))
+    assert bool(torch.isfinite(r2["preds"]).all()) and float(r2["loss_g"]) < float(r["loss_g"])
+
+
 def test_intermediate_taps_match_oracle(dev, golden):
     """Stage by stage against the CPU oracle AND the reference's own taps (e2e_32.npz) on the same batch: IDW output,
     Convsin output, deepest pooled tensor, Decoder[3], both UPPos outputs named in p2igan.py:91-105, and the two
