@@ -356,15 +356,18 @@ def test_idw_matches_oracle_and_golden(ops, kind, golden):
     assert rel_err(dv.cpu().numpy(), src.grad.numpy()) < TOL_WGRAD
 
 
-@pytest.mark.parametrize("kind,shape", [("gauge", (2, 16, 64, 64)), ("gauge", (1, 16, 40, 96)), ("block", (2, 16, 64, 64)), ("pergauge", (2, 8, 48, 48))])
+@pytest.mark.parametrize("kind,shape", [("gauge", (2, 16, 64, 64)), ("gauge", (1, 16, 40, 96)), ("block", (2, 16, 64, 64)), ("pergauge", (2, 8, 48, 48)),
+                                        ("gauge", (1, 8, 12, 20)), ("one_empty", (3, 16, 32, 32))])
 def test_idw_two_pass_search_equals_index_order_scan(ops, monkeypatch, kind, shape):
     """ops.idw_fwd's default (outward search + replay of the tied voxels, p2i_idw_fwd_ws) against the single-kernel replay of the
     reference's scan (P2I_IDW_FAST=0, the kernel the oracle / golden tests pinned in rounds 1-2): the same four points for every voxel
     -- compared as sets: ties among the four may come out in another order -- and outputs equal to summation order."""
     from p2igan_bench.utils import seeded
     B, T, H, W = shape
-    if kind == "gauge":                      # one mask for every frame: the (t-1)/(t+1) ties the replay pass exists for
-        mk = seeded.gauge_mask(H, W, 40).reshape(1, 1, H, W).expand(B, T, H, W).contiguous()
+    if kind in ("gauge", "one_empty"):       # one mask for every frame: the (t-1)/(t+1) ties the replay pass exists for
+        mk = seeded.gauge_mask(H, W, 40 if H * W >= 1024 else 12).reshape(1, 1, H, W).expand(B, T, H, W).contiguous()
+        if kind == "one_empty":              # a sample without points between two with: zeros, and nothing of it in the replay list
+            mk[1] = 0
     elif kind == "block":
         mk = seeded.block_mask(H, W, 8, seed=5).reshape(1, 1, H, W).expand(B, T, H, W).contiguous()
     else:                                    # a different mask per frame and sample, some frames empty
@@ -384,8 +387,10 @@ def test_idw_two_pass_search_equals_index_order_scan(ops, monkeypatch, kind, sha
     assert torch.equal(a, b), f"{int((a != b).any(dim=1).sum())} voxels select other points"
     assert float((out - out0).abs().max()) <= 4e-7 * float(out0.abs().max())
     assert float((selw.view(-1, 4).sort(dim=1).values - selw0.view(-1, 4).sort(dim=1).values).abs().max()) <= 1e-6
-    if kind == "gauge":
+    if kind == "gauge" and H * W >= 1024:
         assert int(counts.min()) > 0                             # the replay pass had voxels to decide
+    if kind == "one_empty":
+        assert int(counts[1]) == 0 and float(out[1].abs().max()) == 0.0
     assert int(counts.max()) < T * H * W // 4, counts
 
 
