@@ -112,17 +112,35 @@ def physical_cores():
     return avail, max(1, min(avail, len(cores)))
 
 
+def collective_evidence(device=None):
+    """What the process group itself saw, for the N > 1 line: the backend's name (nccl = RCCL on ROCm), the number of ranks that
+    took part in a SUM all-reduce of ones, and the library version when torch exposes it.  A line whose n_gpus came from the
+    environment only cannot show that a collective ran; this does."""
+    one = torch.ones(1, device=device) if device is not None else torch.ones(1)
+    dist.all_reduce(one)
+    ev = {"backend": dist.get_backend(), "ranks_seen": int(one.item()), "world_size": dist.get_world_size()}
+    try:
+        if device is not None:
+            ev["nccl_version"] = ".".join(map(str, torch.cuda.nccl.version()))
+    except Exception:
+        pass
+    return ev
+
+
 def stub_main(args, world, rank):
     """Launcher self-test (tests/test_bench_launch_cpu.py; P2I_BENCH_STUB=1 only): same rank / barrier / max-over-ranks /
     one-JSON-line plumbing over gloo on CPU with a stand-in step.  Never a measurement: the line says so."""
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     buf = torch.ones(1024) * (rank + 1)
+    exch = [0.0]
 
     def step():
         time.sleep(0.002)
         if world > 1:
+            t_ = time.perf_counter()
             dist.all_reduce(buf)
+            exch[0] += time.perf_counter() - t_
 
     for _ in range(args.warmup):
         step()
@@ -139,11 +157,18 @@ def stub_main(args, world, rank):
     dt = float(tt)
     if os.environ.get("P2I_BENCH_STUB_FAIL_RANK") == str(rank):
         raise SystemExit(3)
+    rccl = None
+    if world > 1:
+        rccl = collective_evidence()
+        rccl["exchange_ms_per_step"] = exch[0] / max(1, args.steps + args.warmup) * 1e3
     if rank == 0:
-        print(json.dumps({"metric": "train frames/sec (128x128x16)", "value": world * args.batch * T * args.steps / dt, "unit": "frames/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                          "data": "STUB STEP (launcher self-test, not a measurement)",
-                          "config": {"global_batch": args.batch * world, "parallelism": "dp%d" % world}}), flush=True)
+        line = {"metric": "train frames/sec (128x128x16)", "value": world * args.batch * T * args.steps / dt, "unit": "frames/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "data": "STUB STEP (launcher self-test, not a measurement)",
+                "config": {"global_batch": args.batch * world, "parallelism": "dp%d" % world}}
+        if rccl is not None:
+            line["rccl"] = rccl
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -376,6 +401,24 @@ def main():
         dt = float(tt)
     ms_per_step = dt / args.steps * 1e3
     value = world * B * T * args.steps / dt
+    rccl = None
+    if world > 1:
+        # what RCCL itself saw + the EXPOSED exchange time of a step: HIP events on the launch stream around the D all-reduce and
+        # around the wait for the generator's bucketed exchange (TrainEngine.exchange_marks), over a few extra steps outside the
+        # timed region
+        rccl = collective_evidence(dev)
+        eng.exchange_marks = []
+        nex = max(2, min(5, args.steps))
+        for _ in range(nex):
+            eng.train_step(frames, masked, masks)
+        torch.cuda.synchronize()
+        tot = {"d": 0.0, "g": 0.0}
+        for kind, e0, e1 in eng.exchange_marks:
+            tot[kind] += e0.elapsed_time(e1)
+        eng.exchange_marks = None
+        rccl.update(exchange_d_ms_per_step=round(tot["d"] / nex, 3), exchange_g_exposed_ms_per_step=round(tot["g"] / nex, 3),
+                    grad_bytes={"d": int(eng.dp.grad.numel() * 4) if eng.dp is not None else 0, "g": int(eng.gp.grad.numel() * 4)},
+                    overlap="generator buckets launched per Decoder level inside the backward" if eng.dp_overlap else "flat all-reduce after the backward")
 
     roofline = None
     extra = {}
@@ -492,6 +535,8 @@ def main():
                            "launch": "hipGraph replay of the whole step" if getattr(eng, "_graph", None) is not None else "eager launches"},
                 "step_tflops": round(GFLOP_PER_SAMPLE_STEP * B * world / (ms_per_step * 1e-3) / 1e3, 2),
                 "roofline": roofline, "cpu_baseline": cpu}
+        if rccl is not None:
+            line["rccl"] = rccl
         line.update(extra)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -214,8 +214,11 @@ int p2i_attn_bwd(const float* x, const float* w0, const float* b0, const float* 
  *   row_start int32 [B*T*(H+1)]  first point of frame t in a row >= y (lets the scan skip, exactly, the
  *             frames / rows that cannot beat the current 4th-nearest distance)
  *   sel_idx int32 [B*Q*4] (indices into the point list), sel_w float [B*Q*4]  (saved for backward)
- * Empty mask => zeros (layer.py:330-332). 0 < N < 4 is an error in the reference (topk k>N);
- * here the output is NaN-free but unspecified and p2i_idw_status reports it. */
+ * Empty mask => zeros (layer.py:330-332).  0 < N < 4 points in a sample is an error in the reference (torch.topk with k > N
+ * raises, layer.py:282).  The library is enqueue-only and cannot raise without a device sync: it writes ZEROS for that sample
+ * (out, sel_idx, sel_w; p2i_idw_bwd then gives a zero gradient), other samples of the batch are unaffected, and pt_count[b]
+ * holds the count for a caller that wants the reference's error (the Python wrapper: P2I_IDW_STRICT=1, one host sync).
+ * Pinned by tests/test_ops_gpu.py::test_idw_fewer_than_four_points_gives_zeros_or_raises. */
 int p2i_idw_fwd(const float* vals_src, const float* mask, const float* grid_x, const float* grid_y,
                 const float* grid_z, float* out, int32_t* pt_pos, int32_t* pt_count, int32_t* frame_count,
                 int32_t* row_start, float* pt_xyzn, int32_t* sel_idx, float* sel_w, int B, int T, int H, int W, float tau,

@@ -525,7 +525,9 @@ __global__ __launch_bounds__(512) void o1_fwd_kernel(const float* __restrict__ x
   float acc = 0.f;
   // loads of a channel are unconditional (clamped offsets, values masked afterwards) so that the loop unrolls and the loads of
   // several channels are in flight together: a conditional load makes hipcc branch around it and wait before the next one
-  const int o_up = up ? -W : 0, o_dn = dn ? W : 0;
+  // (a lane below the image's last row -- odd H -- is `up` but not `mid`: it reads from the tensor base x, where a row offset of -W
+  // would leave the allocation; its value only feeds pixels that are never stored)
+  const int o_up = (up && mid) ? -W : 0, o_dn = (dn && mid) ? W : 0;
   const int nc = (Cin - wave + 7) >> 3;              // channels of this wave: wave, wave + 8, ...
   if (!wide) {
     const bool lz = col == 0, rz = col == 31;
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(512) void o1_fwd_kernel(const float* __restrict__ x
     const float* xr = x + (size_t)b * Cin * HW + (size_t)h_c * W;      // row start (clamped row)
     const int wl = lok ? w - 1 : 0, wm = in_w ? w : 0, wr = rok ? w + 1 : 0;
     const bool hu = h - 1 >= 0 && h - 1 < H, hm = h < H, hd = h + 1 < H;
-    const int ou = hu ? -W : 0, od = hd ? W : 0;
+    const int ou = (hu && hm) ? -W : 0, od = hd ? W : 0;      // (row h == H is clamped to H - 1: no row above it when H == 1)
 #pragma unroll 2
     for (int ci = 0; ci < nc; ++ci) {
       const int c = wave + 8 * ci;

@@ -39,11 +39,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 }
 
 // parameter gradients only (the block's input is data).  Pixels whose dout is all zero (every non-gauge pixel: the IDW scatter
-// touches gauge voxels only) are skipped.  A pixel's contribution is two rank-1 updates (dg ⊗ h, T x T each) + two bias rows.
-// The first version let each active LANE add its 2 (T*T + T) products into LDS with atomics: one lane, ~550 dependent LDS
-// atomics, 122 us per launch with ~1 active pixel per block.  Now the active pixels of a block are listed in LDS (their four
-// T-vectors) in rounds of ATTN_LIST entries and EVERY thread owns parameter elements and sums over the list: no LDS atomics, a fixed
-// summation order inside the block; one global atomic per parameter and block at the end (blocks without an active pixel skip it).
+// touches gauge voxels only) are skipped.  A pixel's contribution is two rank-1 updates (dg (x) h, T x T each) + two bias rows.
+// Round 1 let each active LANE add its 2 (T*T + T) products into LDS with atomics (~550 dependent LDS atomics per lane, 122 us per
+// launch with ~1 active pixel per block); rounds 2-3 listed the active pixels' four T-vectors in LDS and let every thread own
+// parameter elements and sum over the list -- but each active lane still ran the whole per-pixel chain (two T x T mat-vecs forward,
+// one backward) on nine T-vectors in registers: at T = 32 that spilled 760 VGPRs to 3 KB of scratch per lane.
+// Now the per-pixel chain is COOPERATIVE too: the block's active pixels are compacted (ballot ranks), and in rounds of ATTN_LIST
+// pixels thread (m, i) computes element i of pixel m's vectors -- row i of each mat-vec from LDS, the T-vectors exchanged through the
+// list -- so a thread holds a handful of scalars whatever T is.  Same summation order per element as before (bias first, then j = 0 ..
+// T-1), a fixed order inside the block, one global atomic per parameter and block at the end (blocks without an active pixel leave).
 constexpr int ATTN_LIST = 32;
 
 template <int T>
@@ -53,90 +57,106 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        float* dw0, float* db0, float* dw1, float* db1, int B, int HW) {
   constexpr int NP = T * T + T;                        // parameters per layer: weight rows then bias
   constexpr int NE = (2 * NP + 255) / 256;             // parameter elements per thread
-  __shared__ float sw[2][NP];
-  __shared__ float lst[ATTN_LIST][4][T];               // per listed pixel: dg1, h0, dg2, h1
+  constexpr int PPT = (ATTN_LIST * T + 255) / 256;     // (listed pixel, element) pairs per thread: 4 / 2 / 1 at T = 32 / 16 / 8
+  constexpr int H0 = 0, H1 = 1, DG2 = 2, DG1 = 3;      // slots of a listed pixel
+  __shared__ float sw[2][NP];                          // [layer][i * T + j], then the bias
+  __shared__ float swT[2][T * T];                      // [layer][j * T + i]: row i of a mat-vec read by consecutive threads i
+  __shared__ float lst[ATTN_LIST][4][T];
+  __shared__ int act[256];                             // pixel of the block's r-th active thread
   __shared__ int wave_cnt[4];
-  for (int i = threadIdx.x; i < T * T; i += blockDim.x) { sw[0][i] = w0[i]; sw[1][i] = w1[i]; }
+  for (int i = threadIdx.x; i < T * T; i += blockDim.x) {
+    const float a = w0[i], c = w1[i];
+    sw[0][i] = a; sw[1][i] = c;
+    const int r = i / T, q = i - r * T;
+    swT[0][q * T + r] = a; swT[1][q * T + r] = c;
+  }
   for (int i = threadIdx.x; i < T; i += blockDim.x) { sw[0][T * T + i] = b0[i]; sw[1][T * T + i] = b1[i]; }
   const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float go[T];
   bool any = false;
   if (p < HW) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) { go[t] = dout[((size_t)b * T + t) * HW + p]; any |= (go[t] != 0.f); }
+    for (int t = 0; t < T; ++t) any |= (dout[((size_t)b * T + t) * HW + p] != 0.f);
   }
   // rank of this thread among the block's active pixels (wave ballots + wave offsets)
   const unsigned long long bal = __ballot(any);
   if (lane == 0) wave_cnt[wave] = __popcll(bal);
-  __syncthreads();                                     // also: sw visible
+  __syncthreads();                                     // also: sw / swT visible
   int rank = __popcll(bal & ((1ull << lane) - 1ull)), nact = 0;
 #pragma unroll
   for (int w = 0; w < 4; ++w) { if (w < wave) rank += wave_cnt[w]; nact += wave_cnt[w]; }
   if (nact == 0) return;                               // block-uniform
+  if (any) act[rank] = p;
 
-  float h0[T], dg1[T], h1[T], dg2[T];
-  if (any) {
-    float g1, a1[T], g2[T], a2[T], dh1[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) h0[t] = x[((size_t)b * T + t) * HW + p];
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-      float g = sw[0][T * T + i];
-#pragma unroll
-      for (int j = 0; j < T; ++j) g += sw[0][i * T + j] * h0[j];
-      g1 = g; a1[i] = h0[i] + h0[i] * g1; h1[i] = a1[i] > 0.f ? a1[i] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-      float g = sw[1][T * T + i];
-#pragma unroll
-      for (int j = 0; j < T; ++j) g += sw[1][i * T + j] * h1[j];
-      g2[i] = g; a2[i] = h1[i] + h1[i] * g;
-    }
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-      const float da2 = a2[i] > 0.f ? go[i] : 0.f;
-      dg2[i] = da2 * h1[i];
-      dh1[i] = da2 * (1.f + g2[i]);
-    }
-#pragma unroll
-    for (int j = 0; j < T; ++j) {
-      float acc = 0.f;
-#pragma unroll
-      for (int i = 0; i < T; ++i) acc += sw[1][i * T + j] * dg2[i];
-      dh1[j] += acc;
-    }
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-      const float da1 = a1[i] > 0.f ? dh1[i] : 0.f;
-      dg1[i] = da1 * h0[i];
-    }
-  }
   // element e of this thread: layer l = e / NP, index q = e % NP; q < T*T: weight (i, j) = (q / T, q % T) <- dg[i] * h[j]; else bias
   float acc[NE];
 #pragma unroll
   for (int k = 0; k < NE; ++k) acc[k] = 0.f;
   for (int r0 = 0; r0 < nact; r0 += ATTN_LIST) {
-    __syncthreads();                                   // previous round consumed
-    if (any && rank >= r0 && rank < r0 + ATTN_LIST) {
-      float (&e)[4][T] = lst[rank - r0];
+    const int n = min(ATTN_LIST, nact - r0);
+    __syncthreads();                                   // act visible / previous round consumed
+    int pm[PPT], pi[PPT];
+    bool ok[PPT];
+    float go[PPT], h0v[PPT], a1[PPT], dh1[PPT];
 #pragma unroll
-      for (int t = 0; t < T; ++t) { e[0][t] = dg1[t]; e[1][t] = h0[t]; e[2][t] = dg2[t]; e[3][t] = h1[t]; }
+    for (int k = 0; k < PPT; ++k) {
+      const int pair = threadIdx.x + 256 * k;
+      pm[k] = pair / T; pi[k] = pair - pm[k] * T;
+      ok[k] = pm[k] < n;                               // (pair < ATTN_LIST * T follows: n <= ATTN_LIST)
+      if (ok[k]) {
+        const size_t o = ((size_t)b * T + pi[k]) * HW + act[r0 + pm[k]];
+        go[k] = dout[o];
+        h0v[k] = x[o];
+        lst[pm[k]][H0][pi[k]] = h0v[k];
+      }
     }
     __syncthreads();
-    const int n = min(ATTN_LIST, nact - r0);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      if (!ok[k]) continue;
+      float g = sw[0][T * T + pi[k]];
+#pragma unroll 8
+      for (int j = 0; j < T; ++j) g += swT[0][j * T + pi[k]] * lst[pm[k]][H0][j];
+      a1[k] = h0v[k] + h0v[k] * g;
+      lst[pm[k]][H1][pi[k]] = a1[k] > 0.f ? a1[k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      if (!ok[k]) continue;
+      float g = sw[1][T * T + pi[k]];
+#pragma unroll 8
+      for (int j = 0; j < T; ++j) g += swT[1][j * T + pi[k]] * lst[pm[k]][H1][j];
+      const float h1i = lst[pm[k]][H1][pi[k]];
+      const float a2 = h1i + h1i * g;
+      const float da2 = a2 > 0.f ? go[k] : 0.f;
+      lst[pm[k]][DG2][pi[k]] = da2 * h1i;
+      dh1[k] = da2 * (1.f + g);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      if (!ok[k]) continue;
+      float s = 0.f;
+#pragma unroll 8
+      for (int i = 0; i < T; ++i) s += sw[1][i * T + pi[k]] * lst[pm[k]][DG2][i];
+      const float d = dh1[k] + s;
+      const float da1 = a1[k] > 0.f ? d : 0.f;
+      lst[pm[k]][DG1][pi[k]] = da1 * h0v[k];
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
       const int e = threadIdx.x + 256 * k;
       if (e >= 2 * NP) continue;
       const int l = e >= NP ? 1 : 0, q = e - l * NP;
+      const int sd = l ? DG2 : DG1, sh = l ? H1 : H0;
       float a = acc[k];
       if (q < T * T) {
         const int i = q / T, j = q % T;
-        for (int m = 0; m < n; ++m) a += lst[m][2 * l][i] * lst[m][2 * l + 1][j];
+        for (int m = 0; m < n; ++m) a += lst[m][sd][i] * lst[m][sh][j];
       } else {
-        for (int m = 0; m < n; ++m) a += lst[m][2 * l][q - T * T];
+        for (int m = 0; m < n; ++m) a += lst[m][sd][q - T * T];
       }
       acc[k] = a;
     }

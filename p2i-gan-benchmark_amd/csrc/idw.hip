@@ -110,30 +110,6 @@ __global__ __launch_bounds__(IDW_CT) void idw_compact_kernel(const float* __rest
   (void)gx; (void)gy; (void)gz;
 }
 
-// ---- 4-NN + IDW.  thread = one query voxel, workgroup = 256 voxels.  The workgroup walks frames / row ranges together (bounds are
-// workgroup-uniform: largest root, smallest |dz|, row span), stages the range's points in LDS with coalesced loads and every lane
-// reads them back as broadcasts, four per trip.  (Scalar loads of the points, tried first in round 3, miss the 16 KB scalar cache
-// -- eight samples' point lists are 160 KB -- and ran 3x slower than even per-lane global loads.)
-//
-// MODE 0 -- the reference's scan replayed for every voxel: points in index order (frame-major, then row-major), a 4-entry max-heap
-//   whose root is replaced on STRICTLY smaller d (libstdc++ partial_sort as torch.topk uses it), exact under ties.
-//   Exact pruning: whole frames / row ranges that provably cannot beat the CURRENT root are skipped: a skipped point has |dz| or
-//   |dy| (hence its computed distance, up to the 2e-6 slack that covers the fp32 cancellation of the |a|^2+|b|^2-2ab chain) above
-//   the root at its turn, so std::partial_sort would not have inserted it either and the heap evolves identically.  (A lane meeting
-//   a point it alone could have skipped rejects it like any other.)
-// MODE 1 -- fast path.  The reference's result depends on the ORDER of its scan only where distances tie: with d1 <= d2 <= d3 <= d4
-//   the four smallest computed distances and d5 the smallest of all others,
-//   * d4 < d5: the SET of selected points is the four nearest whatever the order (a max-heap that replaces its root on strictly
-//     smaller d ends with exactly those); ties AMONG the four only permute equal weights in the four-term output sum (<= 1 ulp);
-//   * d4 == d5: which of the tied points is kept depends on the heap's history -- such voxels (3-4 % with a gauge mask shared by all
-//     frames: the same gauge in frames t-1 and t+1 is equidistant from every voxel of frame t, and the fp32 chain rounds both to
-//     the same value often enough) are appended to `amb` and left to MODE 2.
-//   Free of the scan order, this pass starts where the neighbours are -- own frame, rows around the voxels, then the rest of the
-//   frame, then frames outwards in both directions until |dz| alone exceeds the workgroup's largest 4th distance -- with the same
-//   pruning bounds; it evaluates ~1/7 of the points the index-order scan has to touch (there every frame in front of the voxel's
-//   own improves the heap).  d5 is tracked over evaluated points only: a pruned point is farther than the root at the time, hence
-//   than the final d4.
-// MODE 2 -- MODE 0 for the voxels MODE 1 listed: amb[b (Q + 1)] of them, listed behind the count.
 // one point against a lane's selection.  (Macros on plain locals, not lambdas: with the heap captured by reference the compiler
 // sinks the conditional heap moves into stores through selected ADDRESSES and the heap ends up in scratch memory.)
 // MODE 0 / 2: the reference's heap on distances; r2 is the fast-reject bound on d^2: r2 = fl(fl(r*r)*(1+2^-20)) > r^2 exactly, so
@@ -219,7 +195,7 @@ __global__ __launch_bounds__(NT) void idw_knn_kernel(const float* __restrict__ v
   }
   const int N = uni(pt_count[b]);
   const size_t qo = (size_t)b * Q + q;
-  if (N < 4) {       // N == 0: zeros (layer.py:330-332); 0 < N < 4: reference raises in topk
+  if (N < 4) {       // N == 0: zeros (layer.py:330-332); 0 < N < 4: the reference raises in topk, here zeros as well (p2i_hip.h)
     if (!active) return;
     out[qo] = 0.f;
     if (sel_idx) {

@@ -31,16 +31,26 @@ class Array:
         self.fill = meta.get("fill_value") or 0
         self.zlib = comp is not None
         self.sep = meta.get("dimension_separator", ".")
-        # decoded chunks of a read-only array, most recently used last (a training window re-reads the same one or two chunks
-        # for every overlapping window of an event; on the GPU box an uncached window read cost 2 ms of stat / open / read)
-        self._cache: "Dict[tuple, np.ndarray]" = {}
-        self._cache_bytes = 0
 
-    CACHE_BYTES = 64 << 20       # per array
+
+    # Decoded chunks of read-only arrays, ONE least-recently-used budget per process shared by every Array (a training window
+    # re-reads the same one or two chunks for every overlapping window of an event; on the GPU box an uncached window read cost
+    # 2 ms of stat / open / read).  Round 3 kept up to 64 MB per ARRAY and a dataset keeps every opened event's Array: host memory
+    # grew with the number of events x DataLoader workers.  P2I_ZARR_CACHE_MB sets the budget (default 256 MB per process).
+    CACHE_BYTES = int(os.environ.get("P2I_ZARR_CACHE_MB", "256")) << 20
+    _lru: "Dict[tuple, np.ndarray]" = {}          # (array path, chunk index) -> decoded chunk, most recently used last
+    _lru_bytes = 0
+
+    @classmethod
+    def cache_clear(cls):
+        Array._lru.clear()
+        Array._lru_bytes = 0
 
     def _chunk(self, idx) -> np.ndarray:
-        hit = self._cache.get(idx)
+        key = (self.path, idx)
+        hit = Array._lru.pop(key, None)
         if hit is not None:
+            Array._lru[key] = hit                  # most recently used last
             return hit
         f = os.path.join(self.path, self.sep.join(map(str, idx)) if idx else "0")
         try:
@@ -51,11 +61,11 @@ class Array:
         if self.zlib:
             raw = zlib.decompress(raw)
         ch = np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks)
-        if ch.nbytes <= self.CACHE_BYTES:
-            while self._cache and self._cache_bytes + ch.nbytes > self.CACHE_BYTES:
-                self._cache_bytes -= self._cache.pop(next(iter(self._cache))).nbytes
-            self._cache[idx] = ch
-            self._cache_bytes += ch.nbytes
+        if ch.nbytes <= Array.CACHE_BYTES:
+            while Array._lru and Array._lru_bytes + ch.nbytes > Array.CACHE_BYTES:
+                Array._lru_bytes -= Array._lru.pop(next(iter(Array._lru))).nbytes
+            Array._lru[key] = ch
+            Array._lru_bytes += ch.nbytes
         return ch
 
     def __getitem__(self, key) -> np.ndarray:

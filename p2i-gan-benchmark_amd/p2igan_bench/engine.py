@@ -188,6 +188,18 @@ class TrainEngine:
             self.phase_marks.append(e)
 
     phase_marks = None      # set to [] to collect 4 events per step: start, after G fwd + rec loss, after the D step, end
+    exchange_marks = None   # set to [] to collect (kind, start event, end event) around the data-parallel exchanges the launch stream
+    #                         WAITS for ("d": D's flat all-reduce; "g": the wait for G's buckets / its flat all-reduce) -- bench.py's rccl{}
+
+    def _exchange(self, kind, fn):
+        if self.exchange_marks is None or not self.gp.grad.is_cuda:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.exchange_marks.append((kind, e0, e1))
+        return out
 
     def _step_direct(self, frames, masked, masks) -> Dict[str, torch.Tensor]:
         """train.py:240-326 with explicit forward / backward calls (see __init__).  Gradient bookkeeping:
@@ -264,7 +276,7 @@ class TrainEngine:
                     net_fns.discriminator_backward(D, cr, dlr, need_x=False, inplace=True, accumulate=True)
                     del cf, cr
                 if self.distributed:
-                    _allreduce_mean(self.dp.grad, self.world)
+                    self._exchange("d", lambda: _allreduce_mean(self.dp.grad, self.world))
                 self.opt_d.step()
                 self._mark()
                 lg, cg = net_fns.discriminator_forward(D, preds, need_x=True, need_p=False, pool=True)
@@ -279,12 +291,12 @@ class TrainEngine:
                 bk = BucketedAllReduce(self.gp.grad, self.world, (lambda t, a: ops.axpy_(t, t, a - 1.0)) if self.gp.grad.is_cuda else None)
                 net_fns.generator_backward(G, S, dgen, inplace=True, on_level_done=lambda lvl: bk.launch(*self.level_range(lvl)))
                 del S
-                bk.finish()
+                self._exchange("g", bk.finish)
             else:
                 net_fns.generator_backward(G, S, dgen, inplace=True)
                 del S
                 if self.distributed:
-                    _allreduce_mean(self.gp.grad, self.world)
+                    self._exchange("g", lambda: _allreduce_mean(self.gp.grad, self.world))
             self.opt_g.step()
             out.update(loss_g=loss_g.reshape(()), preds=preds)
             self._mark()

@@ -744,6 +744,16 @@ def _grid_tables(T, H, W, device):
     return _LINSPACE[key]
 
 
+def _idw_strict(pt_count):
+    """A sample with 1..3 mask points: the reference raises in torch.topk(k=4) (layer.py:282); the kernels write zeros for it
+    (include/p2i_hip.h) because raising needs the point counts on the host -- a device sync in the middle of the step.
+    P2I_IDW_STRICT=1 pays that sync and raises the reference's error."""
+    if _os.environ.get("P2I_IDW_STRICT", "0") == "1":
+        n = pt_count.cpu()
+        if bool(((n > 0) & (n < 4)).any()):
+            raise RuntimeError("selected index k out of range (idw_3d_knn needs at least 4 mask points per sample, got %s)" % n.tolist())
+
+
 def idw_fwd(vals_src, mask, tau=0.05, save=True, _amb_out=None):
     """vals_src, mask: (B,T,H,W).  Returns out and the saved selection (pt_pos, sel_idx, sel_w)."""
     lib = _hip.load()
@@ -769,10 +779,12 @@ def idw_fwd(vals_src, mask, tau=0.05, save=True, _amb_out=None):
                                       float(tau), _stream()), "p2i_idw_fwd_ws")
         if _amb_out is not None:                       # tests: the per-sample count of voxels left to the replay pass
             _amb_out.append(amb)
+        _idw_strict(pt_count)
         return out, (pt_pos, pt_count, sel_idx, sel_w)
     _hip.check(lib.p2i_idw_fwd(_ptr(vals_src), _ptr(mask), _ptr(gx), _ptr(gy), _ptr(gz), _ptr(out), _ptr(pt_pos), _ptr(pt_count),
                                _ptr(frame_count), _ptr(row_start), _ptr(pt_xyzn), _ptr(sel_idx), _ptr(sel_w), B, T, H, W, float(tau), _stream()),
                "p2i_idw_fwd")
+    _idw_strict(pt_count)
     return out, (pt_pos, pt_count, sel_idx, sel_w)
 
 

@@ -131,10 +131,14 @@ class Trainer:
         return [t.permute(0, 1, 4, 2, 3).contiguous().to(self.device, non_blocking=True) for t in batch]   # train.py:468-473
 
     def _evaluate_rec_loss(self, loader, max_frames=None):
-        """train.py:369-382 on the HIP path; under data parallelism the evaluation loaders shard the split without padding and
-        (loss sum weighted by samples, sample count) are all-reduced, so that every rank (and the best.pt decision on rank 0)
-        sees the mean over the whole split with every sample counted once.  Returns (mean loss, number of samples)."""
+        """train.py:369-382 on the HIP path.  One process (world == 1): the reference's own figure, the mean of the BATCH means
+        (total_loss / batches) -- a short last batch weighs as much as a full one, and val_loss / the best.pt decision equal the
+        reference's.  Data parallel (world > 1, no reference behaviour: its Trainer is single-process): the evaluation loaders shard
+        the split without padding, so ranks see different batch counts and sizes; there (loss sum weighted by samples, sample count)
+        are all-reduced and every rank (and the best.pt decision on rank 0) sees the mean over the whole split with every sample
+        counted once.  Returns (mean loss, number of samples)."""
         tot = torch.zeros(2, dtype=torch.float64, device=self.device)
+        bsum, nb = torch.zeros((), dtype=torch.float64, device=self.device), 0
         skipped = 0
         for batch in loader:
             fr, mk, ms = self._batch(batch)
@@ -143,13 +147,17 @@ class Trainer:
             if fr.shape[1] != self.generator.length:
                 skipped += fr.shape[0]
                 continue
-            tot[0] += self.engine.eval_rec_loss(fr, mk, ms).double() * fr.shape[0]     # batch mean -> sample-weighted sum
+            bl = self.engine.eval_rec_loss(fr, mk, ms).double()
+            bsum, nb = bsum + bl, nb + 1
+            tot[0] += bl * fr.shape[0]                                                   # batch mean -> sample-weighted sum
             tot[1] += fr.shape[0]
         if skipped:
             logging.warning("evaluation skipped %d sample(s) whose length differs from the generator's %d frames", skipped, self.generator.length)
         if self.world > 1:
             torch.distributed.all_reduce(tot)
         ns = int(tot[1])
+        if self.world == 1:
+            return (float(bsum) / nb if nb else float("nan")), ns
         return (float(tot[0]) / ns if ns else float("nan")), ns
 
     def train(self, tracker):
@@ -157,7 +165,8 @@ class Trainer:
             if hasattr(self.train_loader.sampler, "set_epoch"):
                 self.train_loader.sampler.set_epoch(epoch)
             run, steps = None, 0
-            # batches arrive on the device one step ahead (pinned staging + copy stream: data/prefetch.py); train.prefetch=false
+            # batches arrive on the device one step ahead (copy stream, pageable source -- pinned staging measured 17 ms slower per batch
+            # on this platform: data/prefetch.py); train.prefetch=false
             # keeps the reference's in-line hand-over (train.py:468-473)
             feed = DevicePrefetcher(self.train_loader, self.device) if self.cfg.get("train", {}).get("prefetch", True) else \
                 (self._batch(b) for b in self.train_loader)

@@ -27,12 +27,16 @@ def test_gpus2_spawns_two_ranks():
     line = _line(r.stdout)
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 16
     assert line["steps"] == 5 and line["ms_per_step"] >= 2.0
+    # the N > 1 line carries what the process group itself saw (bench.py::collective_evidence), not only WORLD_SIZE
+    assert line["rccl"]["backend"] == "gloo" and line["rccl"]["ranks_seen"] == 2 and line["rccl"]["world_size"] == 2
+    assert line["rccl"]["exchange_ms_per_step"] >= 0.0
 
 
 def test_gpus1_stays_single_process():
     r = _run(["--gpus", "1", "--steps", "3", "--warmup", "0"])
     assert r.returncode == 0, r.stderr[-2000:]
-    assert _line(r.stdout)["n_gpus"] == 1
+    line = _line(r.stdout)
+    assert line["n_gpus"] == 1 and "rccl" not in line
 
 
 def test_failing_rank_fails_the_launch():

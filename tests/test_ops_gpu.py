@@ -54,7 +54,13 @@ CONV_CASES = [
     ("d3d_tstride64", 3, 2, 64, 128, (6, 16, 16), (3, 3, 3), (2, 1, 1), (1, 1, 1), "leaky", True, False),     # wgrad_x6 / x6c with t slices, t stride 2
     ("d3d_t1_64", 3, 1, 64, 64, (5, 8, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1), "none", True, True),             # t stride 1, odd T
     ("d2d_256_to1_wide", 2, 2, 40, 1, (9, 70), (3, 3), (1, 1), (1, 1), "none", True, False),                  # o1_fwd_kernel: three column tiles, odd rows
+    ("d2d_to1_narrow_oddh", 2, 2, 40, 1, (9, 20), (3, 3), (1, 1), (1, 1), "none", True, False),               # o1_fwd_kernel: one column tile, odd rows (the last row tile's lower lanes)
+    ("d2d_to1_crop100", 2, 1, 256, 1, (25, 25), (3, 3), (1, 1), (1, 1), "none", True, False),                 # a 100 x 100 crop's last 2-D layer
+    ("d2d_to1_h1_wide", 2, 1, 16, 1, (1, 40), (3, 3), (1, 1), (1, 1), "none", True, False),                   # a single row, two column tiles
 ]
+
+
+O1_CASES = ("d2d_to1", "d2d_256_to1_wide", "d2d_to1_narrow_oddh", "d2d_to1_crop100", "d2d_to1_h1_wide")      # o1_fwd_kernel's
 
 
 def _act_cpu(y, act):
@@ -204,12 +210,12 @@ def test_conv_fwd_dgrad_wgrad(ops, engine, case):
     wp_f, wp_d = ops.weight_pack(w.detach().to(dev))
     xg = x.detach().to(dev)
     yg = ops.conv_fwd(spec, xg, wp_f, bias.detach().to(dev) if has_bias else None, res.to(dev) if has_res else None, act_code)
-    x6c_layer = engine.startswith("x6c") and nd == 2 and k == (3, 3) and st == (1, 1) and name not in ("g3x3_tiny4", "g3x3_w128", "d2d_to1", "g3x3_1024_atomic", "d2d_256_to1_wide")
+    x6c_layer = engine.startswith("x6c") and nd == 2 and k == (3, 3) and st == (1, 1) and name not in ("g3x3_tiny4", "g3x3_w128", "g3x3_1024_atomic") + O1_CASES
     # (those three: a 256-position tile spans 16 or 4 images / is 2 x 128 + halo -- patches above the 384-pixel limit, f32 engine)
     x6c_layer = x6c_layer or (engine.startswith("x6c") and name in ("d3d_tstride16", "d3d_t1_16", "d3d_tstride64", "d3d_t1_64"))
     if x6c_layer and Cin % 16 == 0:
         assert _last_plan(ops)[5] == 7, (name, _last_plan(ops))
-    if name in ("d2d_to1", "d2d_256_to1_wide"):
+    if name in O1_CASES:
         assert _last_plan(ops)[5] == 3, (name, _last_plan(ops))      # single-output-channel bandwidth kernel (o1_fwd_kernel)
     assert rel_err(yg.cpu().numpy(), out.detach().numpy()) < TOL_OP
 
@@ -305,9 +311,12 @@ def test_spectral_norm(ops, shape):
     assert abs(float(s2) - float(sigma)) < 1e-4 * abs(float(sigma))
 
 
-def test_attention_block(ops):
+@pytest.mark.parametrize("T,frac", [(16, 0.2), (8, 0.2), (32, 0.2), (32, 1.0), (16, 0.004)], ids=["T16", "T8", "T32", "T32_dense", "T16_sparse"])
+def test_attention_block(ops, T, frac):
+    """frac = share of pixels with a non-zero output gradient (the backward kernel lists those per block, ATTN_LIST = 32 per round:
+    0.2 of 240 pixels is two rounds, 1.0 eight, 0.004 blocks without any)."""
     from oracle import p2i_oracle as orc
-    B, T, H, W = 2, 16, 12, 20
+    B, H, W = 2, 12, 20
     x = _rand(B, T, H, W, seed=1).abs()
     w0 = _rand(T, T, 1, seed=2, scale=0.3).requires_grad_(True)
     b0 = _rand(T, seed=3, scale=0.1).requires_grad_(True)
@@ -315,7 +324,7 @@ def test_attention_block(ops):
     b1 = _rand(T, seed=5, scale=0.1).requires_grad_(True)
     xs = x.permute(0, 2, 3, 1).contiguous().view(B * H * W, T, 1)
     o = orc.attention_block(orc.attention_block(xs, w0, b0), w1, b1).view(B, H, W, T).permute(0, 3, 1, 2)
-    gout = _rand(B, T, H, W, seed=6) * (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(7)) < 0.2)
+    gout = _rand(B, T, H, W, seed=6) * (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(7)) < frac)
     o.backward(gout)
     dev = "cuda"
     args = [t.detach().to(dev).contiguous() for t in (x, w0, b0, w1, b1)]
@@ -392,6 +401,61 @@ def test_idw_two_pass_search_equals_index_order_scan(ops, monkeypatch, kind, sha
     if kind == "one_empty":
         assert int(counts[1]) == 0 and float(out[1].abs().max()) == 0.0
     assert int(counts.max()) < T * H * W // 4, counts
+
+
+@pytest.mark.parametrize("H,block,bwd", [(96, 4, True), (128, 4, False)], ids=["96_block4_N9216", "128_block4_N16384"])
+def test_idw_dense_mask_matches_oracle(ops, H, block, bwd):
+    """The densest masks the loader can draw (`sti` block 4, sti_dataset.py:37-62: one point per 4 x 4 cell, the same cells in every
+    frame): N = 9 216 (96 x 96) and 16 384 (128 x 128) points per sample.  These reach what the gauge-mask tests never do: MODE 1's
+    LDS window reloaded many times per workgroup (frames t-2 .. t+2 alone hold 2 880 / 5 120 points against a 1 024-point window)
+    and idw_bwd_kernel's global-atomic branch (N > 8 192 points do not fit its LDS accumulator).  0 mismatching voxels against the
+    pinned C restatement (layer.py:259-293), the backward against autograd of the oracle."""
+    from oracle import p2i_oracle as orc
+    from p2igan_bench.utils import seeded
+    T, W = 16, H
+    mk = seeded.block_mask(H, W, block, seed=3).reshape(1, 1, H, W).expand(1, T, H, W).contiguous()
+    assert int(mk[0].sum()) == T * (H // block) * (W // block)
+    src = _rand(1, T, H, W, seed=3).abs().requires_grad_(bwd)
+    tz, ty, tx, pts = orc.mask_points(mk[0])
+    ref = orc.idw_3d_knn(pts, src[0][tz, ty, tx], (T, H, W)).unsqueeze(0)
+    amb = []
+    og, saved = ops.idw_fwd(src.detach().cuda(), mk.cuda(), _amb_out=amb)
+    assert int(saved[1][0]) == pts.shape[0]
+    e = (og.cpu() - ref.detach()).abs()
+    bad = int((e > 1e-5 * float(ref.detach().abs().max())).sum())
+    assert bad == 0, f"{bad} voxels differ from the oracle"
+    assert 0 < int(amb[0][0]) < T * H * W // 2                      # the replay pass had rank-4/5 ties to decide
+    if bwd:
+        gout = _rand(1, T, H, W, seed=4)
+        ref.backward(gout)
+        dv = ops.idw_bwd(gout.cuda(), saved)
+        assert rel_err(dv.cpu().numpy(), src.grad.numpy()) < TOL_WGRAD
+
+
+def test_idw_fewer_than_four_points_gives_zeros_or_raises(ops, monkeypatch):
+    """0 < N < 4 points in a sample: the reference raises in torch.topk(k=4) (layer.py:282, "selected index k out of range").  The
+    HIP path cannot raise without a device-to-host sync in the middle of the step; its documented behaviour (include/p2i_hip.h,
+    p2i_idw_fwd) is zeros for that sample -- like the empty mask of layer.py:330-332 -- with the other samples unaffected, a zero
+    gradient, and the reference's error with P2I_IDW_STRICT=1 (one host sync per call)."""
+    from p2igan_bench.utils import seeded
+    B, T, H, W = 3, 16, 16, 16
+    mk = seeded.gauge_mask(H, W, 12).reshape(1, 1, H, W).expand(B, T, H, W).contiguous()
+    mk[1] = 0
+    mk[1, 3, 5, 7] = 1
+    mk[1, 9, 2, 2] = 1
+    mk[1, 9, 11, 4] = 1                                              # sample 1: three points in all
+    src = _rand(B, T, H, W, seed=3).abs().cuda()
+    out, saved = ops.idw_fwd(src, mk.cuda())
+    assert int(saved[1][1]) == 3
+    assert float(out[1].abs().max()) == 0.0 and float(out[0].abs().max()) > 0 and float(out[2].abs().max()) > 0
+    single, _ = ops.idw_fwd(src[2:].contiguous(), mk[2:].contiguous().cuda())
+    assert torch.equal(single[0], out[2])
+    dv = ops.idw_bwd(torch.ones_like(out), saved)
+    assert float(dv[1].abs().max()) == 0.0 and float(dv[0].abs().max()) > 0
+    monkeypatch.setenv("P2I_IDW_STRICT", "1")
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.idw_fwd(src, mk.cuda())
+    ops.idw_fwd(src[::2].contiguous(), mk[::2].contiguous().cuda())     # samples with >= 4 points (or none) pass the strict check
 
 
 def test_idw_empty_mask(ops):
