@@ -26,6 +26,15 @@
 
 namespace p2i {
 
+#ifdef P2I_STAMP
+// diagnostic build (tools/build_stamp.sh, tools/stamp_wgrad_x6.py): phase stamps and KNOCK-OUT variants of the tile loop (DIAG bits:
+// 1 no global loads, 2 no split / LDS writes, 4 no MFMAs, 8 no operand reads) -- wrong results, read times only; never in the product
+extern __device__ unsigned long long* p2i_stamp_buf;
+#define WX_NOW(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WX_NOW(v) do { } while (0)
+#endif
+
 typedef short s16x4w __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
@@ -90,9 +99,13 @@ __device__ __forceinline__ bf16x8w wx_read_tr_s4(const unsigned char* base, int 
   return __builtin_bit_cast(bf16x8w, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <bool S4>
+template <bool S4, int DIAG = 0>
 __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+#ifdef P2I_STAMP
+  unsigned long long st_entry, st_loop0 = 0, st_loop1 = 0, st_bar = 0, st_t;
+  WX_NOW(st_entry);
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tg = wave >> 2, kh = (wave >> 1) & 1, mh = wave & 1;        // tap group, x-channel half, dy-channel half
   const int i16 = lane & 15, g16 = (lane >> 4) & 1, lhi = lane >> 5, l31 = lane & 31;
@@ -222,6 +235,7 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
   }
   __syncthreads();
   int cur = 0;
+  WX_NOW(st_loop0);
   for (; t < g.ntiles; t += gridDim.x) {
     const int tn = t + gridDim.x;
     const bool more = tn < g.ntiles;
@@ -252,13 +266,18 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
       const int ks = ST_KS[i], k = ST_K[i];
       const bool pre_a = i + 2 < NSTEP;
       const bool pre_b = ks + 1 < WX_TH && (i == 0 || ST_KS[i - 1] != ks);      // first step of a K-step: fetch the next K-step's dy
-      if (i < 8) load_chunk(i);
-      if (i >= 9) split_chunk(i - 9, nbuf);
-      if (pre_a) load_a((i + 2) % 3, i + 2);
-      if (pre_b) load_b((ks + 1) & 1, ks + 1);
+      if (i < 8 && !(DIAG & 1)) load_chunk(i);
+      if (i >= 9 && !(DIAG & 2)) split_chunk(i - 9, nbuf);
+      if (pre_a && !(DIAG & 8)) load_a((i + 2) % 3, i + 2);
+      if (pre_b && !(DIAG & 8)) load_b((ks + 1) & 1, ks + 1);
+      if (!(DIAG & 4)) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
-        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Av[i % 3][PA[q]], Bv[ks & 1][PB[q]], acc[k], 0, 0, 0);
+        for (int q = 0; q < 6; ++q)
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Av[i % 3][PA[q]], Bv[ks & 1][PB[q]], acc[k], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) asm volatile("" :: "v"(Av[i % 3][pl]), "v"(Bv[ks & 1][pl]));      // keep the reads alive
+      }
       // interleave: per MFMA one (two) operand reads and a share of the staging work
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
@@ -271,9 +290,16 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef P2I_STAMP
+    WX_NOW(st_t);
+#endif
     __syncthreads();
+#ifdef P2I_STAMP
+    { unsigned long long t2; WX_NOW(t2); st_bar += t2 - st_t; }
+#endif
     cur ^= 1;
   }
+  WX_NOW(st_loop1);
 
   // ---- store / accumulate the [tap][c][o] tile.  Own taps go straight out; group 1 parks its share of the centre tap in LDS
   // (the buffers are free now) and group 0 adds it to its own.
@@ -318,6 +344,14 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
   };
   if (g.partial) emit([](float* o, float v) { *o = v; });
   else emit([](float* o, float v) { atomicAdd(o, v); });
+#ifdef P2I_STAMP
+  if (p2i_stamp_buf && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long st_end; WX_NOW(st_end);
+    unsigned long long* o = p2i_stamp_buf + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wave) * 8;
+    o[0] = st_loop0 - st_entry; o[1] = st_loop1 - st_loop0; o[2] = st_end - st_loop1; o[3] = st_bar; o[4] = st_entry; o[5] = st_end;
+  }
+#endif
 }
 
 
@@ -555,6 +589,17 @@ int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float*
   // conflict-free row assignment of the transposed reads (wx_read_tr_s4): the default; P2I_WGRAD_X6_S4=0 keeps round 2's rows (A/B, read
   // per call).  Measured in one box (gpurun_out/r03x/wg_s0.log, wg_s4.log, wg_s0b.log; PMC: gpurun_out/r03x/pmc): conflict cycles 43 % ->
   // 0.5 % of the LDS cycles, launch time within 1 % (66.5-71.5 us either way): the transposed reads were never what the kernel waits for.
+#ifdef P2I_STAMP
+  else if (getenv("P2I_WGRAD_DIAG") && atoi(getenv("P2I_WGRAD_DIAG")) != 0) {
+    const int dg = atoi(getenv("P2I_WGRAD_DIAG"));
+    const dim3 gr(ns, ncb, nco * d->kt);
+#define WX_DIAG_CASE(n) case n: { static bool a_ = false; if (!a_) { (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel<true, n>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a_ = true; } \
+      hipLaunchKernelGGL((wgrad_x6_kernel<true, n>), gr, dim3(512), 2 * WX_BUF + 1024, s, g); break; }
+    switch (dg) { WX_DIAG_CASE(1) WX_DIAG_CASE(2) WX_DIAG_CASE(3) WX_DIAG_CASE(4) WX_DIAG_CASE(8) WX_DIAG_CASE(12) WX_DIAG_CASE(11) WX_DIAG_CASE(7)
+      default: hipLaunchKernelGGL(wgrad_x6_kernel<true>, gr, dim3(512), 2 * WX_BUF + 1024, s, g); }
+#undef WX_DIAG_CASE
+  }
+#endif
   else if (!(getenv("P2I_WGRAD_X6_S4") && atoi(getenv("P2I_WGRAD_X6_S4")) == 0))
     hipLaunchKernelGGL(wgrad_x6_kernel<true>, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
   else hipLaunchKernelGGL(wgrad_x6_kernel<false>, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);

@@ -236,14 +236,13 @@ class TrainEngine:
                         # slots gives exactly that gradient); the fake half adds its weight gradients later -- two addends, the
                         # same sum in either order
                         lr2, cr2 = net_fns.discriminator_forward(D, frames, need_x=False, need_p=True, pool=True, prep=dprep_r)
-                        if capturing:                    # (hipGraph capture: the backward's own side stream nested in this one ends
-                            return lr2, cr2              # capture_end in a segmentation fault on ROCm 7.2 -- forward only then)
+                        # (the backward's weight gradients run in line here: a side stream forked from this side stream ends hipGraph
+                        # capture in a segmentation fault on ROCm 7.2 -- ops._SIDE_DEPTH, tools/graph_nested_fork.py)
                         _, dlr2, _ = ops.gan_loss_d(lr2, lr2, self.gan_type, self.real_label, self.fake_label)
                         self.dp.zero_grad()
                         net_fns.discriminator_backward(D, cr2, dlr2, need_x=False, inplace=True, accumulate=False)
                         return lr2, None
 
-                    capturing = torch.cuda.is_current_stream_capturing()
                     real_out = side.run(real_pass, frames)
             preds, S = net_fns.generator_forward(G, masked, masks, need_grad=True, prep=gprep, weights_ready=ready)
             if side is not None and self.use_gan:

@@ -192,8 +192,12 @@ LATE_JOIN = _os.environ.get("P2I_LATE_JOIN", "1") != "0"       # generator_backw
 
 
 def _side_of(net, device):
-    """The network's side stream (ops.SideStream) for weight-gradient kernels, or None when disabled."""
+    """The network's side stream (ops.SideStream) for weight-gradient kernels, or None when disabled -- or when the caller already
+    runs on a side stream (TrainEngine runs D's real half on the generator's): streams are forked from the step's origin stream only
+    (a fork of a fork crashes hipGraph capture on ROCm 7.2, see ops._SIDE_DEPTH; P2I_NESTED_SIDE=1 allows it for eager A/B runs)."""
     if not SIDE_WGRAD:
+        return None
+    if ops.side_depth() > 0 and _os.environ.get("P2I_NESTED_SIDE", "0") != "1":
         return None
     sd = getattr(net, "_side", None)
     if sd is None or sd.stream.device != device:

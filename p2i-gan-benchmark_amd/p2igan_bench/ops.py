@@ -232,6 +232,18 @@ def _wgrad_scratch(device):
     return buf
 
 
+# Depth of SideStream.run calls on the Python stack.  A side stream is only ever forked from the step's ORIGIN stream: forking a
+# stream from a stream that is itself a fork (a SideStream used inside another SideStream.run) is legal in the CUDA model but ends
+# hipGraph capture in a segmentation fault on ROCm 7.2 -- reproduced with torch tensors only by tools/graph_nested_fork.py (cases
+# `nested*`: SIGSEGV; `flat*`: fine; gpurun_out/r4a/nested_fork.log).  models/p2igan.py::_side_of therefore hands out no side stream
+# while another one is running (depth > 0): the nested work runs in line on the current side stream, eager and captured alike.
+_SIDE_DEPTH = 0
+
+
+def side_depth() -> int:
+    return _SIDE_DEPTH
+
+
 class SideStream:
     """A second HIP stream for work that nothing on the main stream waits for until a join: the weight-gradient kernels of a
     backward pass (each needs only tensors the data-gradient chain has already produced, and its result is consumed once per
@@ -248,13 +260,15 @@ class SideStream:
         ev = torch.cuda.Event()
         ev.record()                                    # everything enqueued on the main stream so far (producers of `tensors`)
         self.stream.wait_event(ev)
-        global _CUR_STREAM
+        global _CUR_STREAM, _SIDE_DEPTH
         prev, _CUR_STREAM = _CUR_STREAM, self.stream.cuda_stream
+        _SIDE_DEPTH += 1
         try:
             with torch.cuda.stream(self.stream):
                 out = fn()
         finally:
             _CUR_STREAM = prev
+            _SIDE_DEPTH -= 1
         self.keep.extend(tensors)
         self.pending = True
         return out
