@@ -229,8 +229,11 @@ int p2i_idw_fwd(const float* vals_src, const float* mask, const float* grid_x, c
  * ~10 % of the distance evaluations of the index-order scan) and lists the voxels it finds tied; pass 2 replays the reference's
  * scan for those only (3-4 % with one gauge mask shared by all frames).  Ties among the four selected points permute equal
  * weights in the 4-term output sum (<= 1 ulp of the output; sel_idx / sel_w order may differ there).
- *   amb int32 [B*(Q+1+ceil(Q/256))]: per sample the number of listed voxels, the lists of pass 1's workgroups (256 slots each)
- *       and their lengths / prefix sums (work buffer). */
+ * Round 4: pass 2 first DECIDES a listed voxel from the points within its (now known) 4th distance D, met in index order -- the
+ * reference's heap holds the four smallest values seen so far, so the first four points with d <= D stay unless a point with d < D
+ * follows them (idw.hip, IDW_CONSIDER_FIXED) -- and only the voxels where one does (~7 %) take the full replay, from a second list.
+ *   amb int32 [B*(2Q+2+ceil(Q/256))]: per sample the number of listed voxels, the lists of pass 1's workgroups (256 slots each) and
+ *       their lengths / prefix sums; behind the B samples' blocks the second list, per sample [count, voxels ...] (work buffer). */
 int p2i_idw_fwd_ws(const float* vals_src, const float* mask, const float* grid_x, const float* grid_y,
                    const float* grid_z, float* out, int32_t* pt_pos, int32_t* pt_count, int32_t* frame_count,
                    int32_t* row_start, float* pt_xyzn, int32_t* sel_idx, float* sel_w, int32_t* amb, int B, int T, int H, int W,

@@ -32,6 +32,23 @@ namespace p2i {
     }                                                                                   \
   } while (0)
 
+// libstdc++ __sort_heap on the 4-entry max-heap -> ascending h0..h3
+#define IDW_SORT_HEAP()                                                                                                          \
+  do {                                                                                                                            \
+    {  /* len 4 -> 3 */                                                                                                           \
+      const float xd = h3d; const int xi = h3i; HE_MOVE(h3, h0);                                                                  \
+      if (h2d < h1d) { HE_MOVE(h0, h1); if (h0d < xd) { HE_MOVE(h1, h0); HE_SET(h0, xd, xi); } else HE_SET(h1, xd, xi); }         \
+      else { HE_MOVE(h0, h2); if (h0d < xd) { HE_MOVE(h2, h0); HE_SET(h0, xd, xi); } else HE_SET(h2, xd, xi); }                   \
+    }                                                                                                                             \
+    {  /* len 3 -> 2 */                                                                                                           \
+      const float xd = h2d; const int xi = h2i; HE_MOVE(h2, h0); HE_MOVE(h0, h1);                                                 \
+      if (h0d < xd) { HE_MOVE(h1, h0); HE_SET(h0, xd, xi); } else HE_SET(h1, xd, xi);                                             \
+    }                                                                                                                             \
+    {  /* len 2 -> 1 */                                                                                                           \
+      const float xd = h1d; const int xi = h1i; HE_MOVE(h1, h0); HE_SET(h0, xd, xi);                                              \
+    }                                                                                                                             \
+  } while (0)
+
 // Wave-uniform values, made so for the compiler: loop bounds and point indices built from them live in SGPRs, the points arrive
 // by scalar loads (s_load_dwordx4 .. x16) and the loop is not exec-masked.  (Round 3: without these the scan loops issued one
 // per-lane global_load_dwordx4 + s_waitcnt vmcnt(0) per point -- a memory round trip per distance.)
@@ -76,7 +93,11 @@ __global__ __launch_bounds__(IDW_CT) void idw_compact_kernel(const float* __rest
     for (int k = 0; k < t; ++k) off += frame_count[b * T + k];
     s_base = off;
     if (t == T - 1) pt_count[b] = off + frame_count[bt];
-    if (t == 0 && amb) amb[(size_t)b * ((size_t)T * H * W + 1 + (T * H * W + 255) / 256)] = 0;      // the count of undecided voxels (idw_knn_kernel<1>)
+    if (t == 0 && amb) {
+      const size_t per = (size_t)T * H * W + 1 + (T * H * W + 255) / 256, nB = gridDim.x / T;
+      amb[(size_t)b * per] = 0;                                        // the count of undecided voxels (idw_knn_kernel<1>)
+      amb[nB * per + (size_t)b * ((size_t)T * H * W + 1)] = 0;         // ... and of those the fixed-bound phase of idw_knn_kernel<2> leaves to the replay
+    }
   }
   __syncthreads();
   int base = s_base;
@@ -140,6 +161,39 @@ __global__ __launch_bounds__(IDW_CT) void idw_compact_kernel(const float* __rest
     }                                                                                   \
   } while (0)
 
+// MODE 2, first phase (round 4): the voxel's 4th distance D is known from MODE 1, so the reference's result can be DECIDED from the points
+// with d <= D alone, met in index order (S = that subsequence).  The reference's max-heap always holds the four smallest VALUES seen
+// so far (a new point replaces the root on strictly smaller d), hence:
+//   * the first four members of S are inserted when they arrive (fewer than four points <= D precede them: the root is a point > D)
+//     and each evicts a point > D;
+//   * a later member with d == D is never inserted (four points <= D are in the heap: root <= D, and the comparison is strict);
+//   * a later member with d < D is inserted and evicts the root, a point with d == D.  With exactly ONE such point in the heap it is
+//     that one; with two or more, which of them sits at the root depends on the heap's whole history -- only then is the voxel left
+//     to the exact replay below (flag amb_; also when anything contradicts D being the 4th distance).
+// Points with d > D never touch the outcome (they are evicted before any point <= D is, the root being the largest), so this scan
+// runs with the FIXED bound D from its first point -- ~1/7 of the points the replay's shrinking root lets through, no heap moves.
+// s0..s3: the current set (any order), ns_ members of S met, nd_ how many of the set have d == D.
+#define IDW_CONSIDER_FIXED(c2v, jv)                                                     \
+  do {                                                                                  \
+    if ((c2v) < r2) {                                                                   \
+      const float dc_ = sqrtf(fmaxf((c2v), 0.f));                                       \
+      if (dc_ <= dq_) {                                                                 \
+        const bool isd_ = dc_ == dq_;                                                   \
+        if (ns_ < 4) {                                                                  \
+          if (ns_ == 0) HE_SET(h0, dc_, (jv)); else if (ns_ == 1) HE_SET(h1, dc_, (jv)); \
+          else if (ns_ == 2) HE_SET(h2, dc_, (jv)); else HE_SET(h3, dc_, (jv));         \
+          ++ns_; nd_ += isd_ ? 1 : 0;                                                   \
+        } else if (!isd_) {                                                             \
+          if (nd_ == 1) {                                                               \
+            if (h0d == dq_) HE_SET(h0, dc_, (jv)); else if (h1d == dq_) HE_SET(h1, dc_, (jv)); \
+            else if (h2d == dq_) HE_SET(h2, dc_, (jv)); else HE_SET(h3, dc_, (jv));     \
+            nd_ = 0;                                                                    \
+          } else amb_ = true;                                                           \
+        }                                                                               \
+      }                                                                                 \
+    }                                                                                   \
+  } while (0)
+
 // ---- 4-NN + IDW.  thread = one query voxel, workgroup = NT voxels.  The workgroup walks frames / row ranges together (bounds are
 // workgroup-uniform: largest root, smallest |dz|, row span), keeps a window of the point list in LDS (loaded with all threads once
 // per 4 NT points -- a gauge mask's frames t-2 .. t+2 are 400 points -- so it waits for global memory once or twice in all) and
@@ -163,8 +217,11 @@ __global__ __launch_bounds__(IDW_CT) void idw_compact_kernel(const float* __rest
 //   frame, then frames outwards in both directions until |dz| alone exceeds the workgroup's largest 4th distance -- with the same
 //   pruning bounds; it evaluates ~1/7 of the points the index-order scan has to touch (there every frame in front of the voxel's
 //   own improves the heap).  d5 is taken over evaluated points only: a pruned point is farther than the 4th at the time.
-// MODE 2 -- MODE 0 for the voxels MODE 1 listed, in the order (MODE 1 workgroup, rank) so that a workgroup's voxels are neighbours
-//   and its pruning bounds stay tight.
+// MODE 2 -- the voxels MODE 1 listed, in the order (MODE 1 workgroup, rank) so that a workgroup's voxels are neighbours and its pruning
+//   bounds stay tight: decided from the points within the known 4th distance (IDW_CONSIDER_FIXED above) where that is possible; the
+//   rest go to a second, flat list and a second MODE 2 launch (flags 3) replays MODE 0's scan for those.  (flags 1: the replay for every
+//   listed voxel, round 3's pass; A/B, tests.)
+// amb2, behind the B samples' amb blocks, per sample: [0] number of voxels left to the replay; [1 ...] the voxels.
 // amb, per sample (nblk1 = MODE 1's workgroups): [0] number of undecided voxels; [1 + 256 g ...] those of workgroup g;
 //   [1 + Q + g] how many those are, turned into their exclusive prefix sums by idw_prefix_kernel.
 constexpr int IDW_MAX_BLK = 1 << 20;                  // (prefix sums of more workgroups than this: single-pass scan instead)
@@ -173,7 +230,7 @@ __global__ __launch_bounds__(NT) void idw_knn_kernel(const float* __restrict__ v
                                                     const float* __restrict__ gy, const float* __restrict__ gz,
                                                     const int32_t* __restrict__ pt_pos, const int32_t* __restrict__ pt_count,
                                                     const int32_t* __restrict__ row_start, const float4* __restrict__ pt_xyzn, float* out, int32_t* sel_idx,
-                                                    float* sel_w, int32_t* amb, int nblk1, int T, int H, int W, float tau) {
+                                                    float* sel_w, int32_t* amb, int nblk1, int T, int H, int W, float tau, int flags) {
   constexpr int NW = NT / 64, WIN = 4 * NT;
   __shared__ float4 spts[WIN];
   __shared__ float sredf[2 * NW];
@@ -182,16 +239,23 @@ __global__ __launch_bounds__(NT) void idw_knn_kernel(const float* __restrict__ v
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q_raw = blockIdx.x * NT + tid;
   int32_t* ambs = amb + (size_t)b * (Q + 1 + nblk1);
-  const int nq = MODE == 2 ? uni(ambs[0]) : Q;
+  // second list (MODE 2, flags & 2): the voxels the fixed-bound phase left undecided, flat: [0] count, [1 ..] voxels
+  int32_t* amb2s = amb + (size_t)gridDim.y * (Q + 1 + nblk1) + (size_t)b * (Q + 1);
+  const bool flat = MODE == 2 && (flags & 2);
+  const int nq = MODE == 2 ? uni(flat ? amb2s[0] : ambs[0]) : Q;
   if (MODE == 2 && (int)(blockIdx.x * NT) >= nq) return;
   const bool active = q_raw < nq;                      // inactive lanes shadow the last voxel: the reductions below need every lane
   int q = active ? q_raw : Q - 1;                      // to hold defined values
   if constexpr (MODE == 2) {
     const int* pre = ambs + 1 + Q;                     // exclusive prefix sums of the per-workgroup counts
     const int d = active ? q_raw : nq - 1;
-    int lo = 0, hi = nblk1;                            // largest g with pre[g] <= d
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= d) lo = mid; else hi = mid; }
-    q = ambs[1 + lo * 256 + (d - pre[lo])];
+    if (flat) {
+      q = amb2s[1 + d];
+    } else {
+      int lo = 0, hi = nblk1;                          // largest g with pre[g] <= d
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= d) lo = mid; else hi = mid; }
+      q = ambs[1 + lo * 256 + (d - pre[lo])];
+    }
   }
   const int N = uni(pt_count[b]);
   const size_t qo = (size_t)b * Q + q;
@@ -223,15 +287,22 @@ __global__ __launch_bounds__(NT) void idw_knn_kernel(const float* __restrict__ v
   float h0d = INF, h1d = INF, h2d = INF, h3d = INF;
   int h0i = 0, h1i = 1, h2i = 2, h3i = 3;
   float r2 = INF;
-  if (MODE != 1) {
-    h0d = sqrtf(fmaxf(dist2(pts[0]), 0.f)); h1d = sqrtf(fmaxf(dist2(pts[1]), 0.f));
-    h2d = sqrtf(fmaxf(dist2(pts[2]), 0.f)); h3d = sqrtf(fmaxf(dist2(pts[3]), 0.f));
-    // __make_heap: parent = 1 (swap with child 3 unless child < parent), then parent = 0
-    if (!(h3d < h1d)) { const float td = h1d; const int ti = h1i; HE_MOVE(h1, h3); HE_SET(h3, td, ti); }
-    const float xd = h0d; const int xi = h0i;
-    HEAP4_REPLACE_ROOT(xd, xi);
-    r2 = h0d * h0d * 1.000001f + 1e-30f;
-  }
+  // MODE 2's first phase decides from the fixed bound D (stashed in out[] by MODE 1); the heap of MODE 0 / the fallback is seeded below
+  const bool fixed_first = MODE == 2 && !(flags & 1);          // (flags & 1: the reference's scan replayed for every voxel of the list)
+  const float dq_ = fixed_first ? out[qo] : 0.f;
+  if (fixed_first) r2 = dq_ * dq_ * 1.000001f + 1e-30f;          // c2 >= r2 implies sqrt_rn(c2) > D (see IDW_CONSIDER_HEAP)
+#define IDW_SEED_HEAP()                                                                                                   \
+  do {                                                                                                                    \
+    h0i = 0; h1i = 1; h2i = 2; h3i = 3;                                                                                   \
+    h0d = sqrtf(fmaxf(dist2(pts[0]), 0.f)); h1d = sqrtf(fmaxf(dist2(pts[1]), 0.f));                                       \
+    h2d = sqrtf(fmaxf(dist2(pts[2]), 0.f)); h3d = sqrtf(fmaxf(dist2(pts[3]), 0.f));                                       \
+    /* __make_heap: parent = 1 (swap with child 3 unless child < parent), then parent = 0 */                              \
+    if (!(h3d < h1d)) { const float td = h1d; const int ti = h1i; HE_MOVE(h1, h3); HE_SET(h3, td, ti); }                  \
+    const float xd = h0d; const int xi = h0i;                                                                             \
+    HEAP4_REPLACE_ROOT(xd, xi);                                                                                           \
+    r2 = h0d * h0d * 1.000001f + 1e-30f;                                                                                  \
+  } while (0)
+  if (MODE != 1 && !fixed_first) IDW_SEED_HEAP();
   // workgroup-uniform reductions (results in SGPRs; two barriers each when the workgroup has more than one wave)
   auto wg_minmax_i = [&](int vmin, int vmax, int& omin, int& omax) __attribute__((always_inline)) {
     vmin = wave_min_i(vmin); vmax = wave_max_i(vmax);
@@ -263,7 +334,8 @@ __global__ __launch_bounds__(NT) void idw_knn_kernel(const float* __restrict__ v
     for (int i_ = tid; i_ < w_hi - w_lo; i_ += NT) spts[i_] = pts[w_lo + i_];                                                  \
     __syncthreads();                                                                                                           \
   } while (0)
-#define IDW_SCAN(lo_expr, hi_expr)                                                                                             \
+#define IDW_SCAN(lo_expr, hi_expr) IDW_SCAN_WITH(IDW_CONSIDER, lo_expr, hi_expr)
+#define IDW_SCAN_WITH(CONS, lo_expr, hi_expr)                                                                                  \
   do {                                                                                                                         \
     const int hi_ = (hi_expr);                                                                                                 \
     int j_ = (lo_expr);                                                                                                        \
@@ -275,10 +347,10 @@ __global__ __launch_bounds__(NT) void idw_knn_kernel(const float* __restrict__ v
         const float4 p0_ = sp_[j_], p1_ = sp_[j_ + 1], p2_ = sp_[j_ + 2], p3_ = sp_[j_ + 3];                                   \
         const float c0_ = dist2(p0_), c1_ = dist2(p1_), c2_ = dist2(p2_), c3_ = dist2(p3_);                                    \
         if (fminf(fminf(c0_, c1_), fminf(c2_, c3_)) < r2) {                                                                    \
-          IDW_CONSIDER(c0_, j_); IDW_CONSIDER(c1_, j_ + 1); IDW_CONSIDER(c2_, j_ + 2); IDW_CONSIDER(c3_, j_ + 3);              \
+          CONS(c0_, j_); CONS(c1_, j_ + 1); CONS(c2_, j_ + 2); CONS(c3_, j_ + 3);                                              \
         }                                                                                                                      \
       }                                                                                                                        \
-      for (; j_ < e_; ++j_) { const float c0_ = dist2(sp_[j_]); IDW_CONSIDER(c0_, j_); }                                       \
+      for (; j_ < e_; ++j_) { const float c0_ = dist2(sp_[j_]); CONS(c0_, j_); }                                               \
     }                                                                                                                          \
   } while (0)
   int w_lo = 0, w_hi = 0;                              // points [w_lo, w_hi) of the list are in LDS (loaded at the first miss, kept across scans)
@@ -301,7 +373,42 @@ __global__ __launch_bounds__(NT) void idw_knn_kernel(const float* __restrict__ v
     return true;
   };
   auto row0 = [&](const int f, const int yy) __attribute__((always_inline)) { return uni(rs[f * (H + 1) + yy]); };
-  if (MODE != 1) {
+  if (fixed_first) {
+    int ns_ = 0, nd_ = 0;
+    bool amb_ = false;
+    for (int f = 0; f < T; ++f) {
+      const int fs = row0(f, 0), fe = row0(f, H);
+      if (fs == fe) continue;
+      int ya, yb;
+      if (!reach(f, ya, yb)) continue;                 // the whole frame is farther than every lane's D
+      IDW_SCAN_WITH(IDW_CONSIDER_FIXED, row0(f, ya), row0(f, yb));
+    }
+    // (fewer than four points within D, or none AT D: D was not the 4th distance -- cannot happen; left to the replay if it does)
+    amb_ = active && (amb_ || ns_ < 4 || nd_ < 1);
+    // voxels the fixed bound cannot decide: appended to the sample's second list (a block per workgroup, reserved with one atomic: the
+    // ORDER of the blocks varies from run to run, no voxel's result depends on the workgroup that replays it -- the pruning is exact)
+    const unsigned long long bal = __ballot(amb_);
+    __syncthreads();
+    if (lane == 0) sredi[2 * NW + wave] = __popcll(bal);
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int k = 0; k < NW; ++k) tot += sredi[2 * NW + k];
+      sredi[0] = tot ? atomicAdd(amb2s, tot) : 0;
+    }
+    __syncthreads();
+    if (amb_) {
+      int off = sredi[0] + __popcll(bal & ((1ull << lane) - 1ull));
+      for (int k = 0; k < wave; ++k) off += sredi[2 * NW + k];
+      amb2s[1 + off] = q;
+      return;
+    }
+    // ascending by distance (the order among equal distances permutes equal weights only): 5-exchange network
+#define IDW_CSWAP(a, b) do { if (b##d < a##d) { const float td_ = a##d; const int ti_ = a##i; HE_MOVE(a, b); HE_SET(b, td_, ti_); } } while (0)
+    IDW_CSWAP(h0, h1); IDW_CSWAP(h2, h3); IDW_CSWAP(h0, h2); IDW_CSWAP(h1, h3); IDW_CSWAP(h1, h2);
+#undef IDW_CSWAP
+  }
+  if (MODE != 1 && !fixed_first) {
     for (int f = 0; f < T; ++f) {
       const int fs = row0(f, 0), fe = row0(f, H);
       if (fe <= 4 || fs == fe) continue;               // points 0..3 seeded the heap
@@ -309,20 +416,8 @@ __global__ __launch_bounds__(NT) void idw_knn_kernel(const float* __restrict__ v
       if (!reach(f, ya, yb)) continue;                 // the whole frame is farther than every lane's root
       IDW_SCAN(max(row0(f, ya), 4), row0(f, yb));
     }
-    // __sort_heap -> ascending h0..h3
-    {  // len 4 -> 3
-      const float xd = h3d; const int xi = h3i; HE_MOVE(h3, h0);
-      if (h2d < h1d) { HE_MOVE(h0, h1); if (h0d < xd) { HE_MOVE(h1, h0); HE_SET(h0, xd, xi); } else HE_SET(h1, xd, xi); }
-      else { HE_MOVE(h0, h2); if (h0d < xd) { HE_MOVE(h2, h0); HE_SET(h0, xd, xi); } else HE_SET(h2, xd, xi); }
-    }
-    {  // len 3 -> 2
-      const float xd = h2d; const int xi = h2i; HE_MOVE(h2, h0); HE_MOVE(h0, h1);
-      if (h0d < xd) { HE_MOVE(h1, h0); HE_SET(h0, xd, xi); } else HE_SET(h1, xd, xi);
-    }
-    {  // len 2 -> 1
-      const float xd = h1d; const int xi = h1i; HE_MOVE(h1, h0); HE_SET(h0, xd, xi);
-    }
-  } else {
+    IDW_SORT_HEAP();
+  } else if (MODE == 1) {
     {   // frames tlo-2 .. thi+2 are one index range: in one window if they fit
       const int p0 = row0(max(tlo - 2, 0), 0), p1 = row0(min(thi + 2, T - 1), H);
       if (p1 - p0 <= WIN && p1 > p0) IDW_LOAD_WINDOW(p0);
@@ -374,6 +469,7 @@ __global__ __launch_bounds__(NT) void idw_knn_kernel(const float* __restrict__ v
       int off = __popcll(bal & ((1ull << lane) - 1ull));
       for (int k = 0; k < wave; ++k) off += sredi[2 * NW + k];
       ambs[1 + blockIdx.x * NT + off] = q;
+      out[qo] = h3d;                                   // the 4th distance D: MODE 2 decides from the points within it
       return;
     }
   }
@@ -394,8 +490,114 @@ __global__ __launch_bounds__(NT) void idw_knn_kernel(const float* __restrict__ v
   }
 }
 #undef IDW_SCAN
+#undef IDW_SCAN_WITH
+#undef IDW_SEED_HEAP
 #undef IDW_LOAD_WINDOW
 #undef IDW_CONSIDER
+
+// The exact replay for the FEW voxels MODE 2's fixed-bound phase leaves undecided (~5 % of the listed ones: ~1 000 per sample, scattered
+// over the volume).  The cooperative workgroup scan above walks the UNION of its lanes' frame / row ranges between barriers: for 256
+// scattered voxels that is most of every frame, and the pass took as long for 1 000 voxels per sample as for 21 000 neighbouring ones
+// (280-550 us, rocprofv3, round 4).  (A wave per voxel -- 64 points evaluated at once, candidates visited in index order through a
+// ballot -- was tried first: the few hundred heap updates of a voxel form one dependent chain of ~100 cycles each, 250-400 us.)
+// Here every LANE replays its own voxel over its OWN ranges (reach()'s bounds from its own root), reading the points from an LDS
+// copy of the sample's list (when it fits: IDW_RW_PCAP points; 79 gauges x 16 frames are 1 264, an `sti` block-10 mask 2 704) at
+// per-lane addresses: no barriers inside the scan, 64 independent chains per wave.  Same comparisons in the same order as MODE 0.
+constexpr int IDW_RW_PCAP = 3072;
+__global__ __launch_bounds__(64) void idw_replay_lane_kernel(const float* __restrict__ vals, const float* __restrict__ gx,
+                                                            const float* __restrict__ gy, const float* __restrict__ gz,
+                                                            const int32_t* __restrict__ pt_pos, const int32_t* __restrict__ pt_count,
+                                                            const int32_t* __restrict__ row_start, const float4* __restrict__ pt_xyzn,
+                                                            float* out, int32_t* sel_idx, float* sel_w, const int32_t* __restrict__ amb,
+                                                            int nblk1, int T, int H, int W, float tau, int use_lds) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rwsm[];     // [IDW_RW_PCAP] points, then [T (H + 1)] row starts (0 bytes: global)
+  const int b = blockIdx.y, HW = H * W, Q = T * HW;
+  const int32_t* amb2s = amb + (size_t)gridDim.y * (Q + 1 + nblk1) + (size_t)b * (Q + 1);
+  const int nq = uni(amb2s[0]);
+  const int N = uni(pt_count[b]);
+  if (N < 4 || (int)(blockIdx.x * 64) >= nq) return;
+  const float4* gpts = pt_xyzn + (size_t)b * Q;
+  const int* grs = row_start + (size_t)b * T * (H + 1);
+  const bool in_lds = use_lds && N <= IDW_RW_PCAP;           // (workgroup-uniform)
+  const float4* sp = reinterpret_cast<const float4*>(rwsm);
+  const int* sr = reinterpret_cast<const int*>(rwsm + sizeof(float4) * IDW_RW_PCAP);
+  if (in_lds) {
+    float4* wp = reinterpret_cast<float4*>(rwsm);
+    int* wr = reinterpret_cast<int*>(rwsm + sizeof(float4) * IDW_RW_PCAP);
+    for (int i = threadIdx.x; i < N; i += 64) wp[i] = gpts[i];
+    for (int i = threadIdx.x; i < T * (H + 1); i += 64) wr[i] = grs[i];
+    __syncthreads();
+  }
+  // (grid-stride: the grid covers Q / 8 voxels per sample at once; a mask whose ties leave more than that loops)
+  for (int v = blockIdx.x * 64 + threadIdx.x; v < nq; v += gridDim.x * 64) {
+  const int q = amb2s[1 + v];
+  const int t = q / HW, rem = q - t * HW, y = rem / W, x = rem - y * W;
+  const float qx = gx[x], qy = gy[y], qz = gz[t];
+  const float a0 = -2.f * qx, a1 = -2.f * qy, a2 = -2.f * qz;
+  const float n1 = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
+  auto dist2 = [&](const float4 p) __attribute__((always_inline)) {
+    float acc = __fmul_rn(a0, p.x);
+    acc = __fmaf_rn(a1, p.y, acc);
+    acc = __fmaf_rn(a2, p.z, acc);
+    acc = __fadd_rn(acc, n1);
+    acc = __fadd_rn(acc, p.w);
+    return acc;
+  };
+  auto point = [&](int j) __attribute__((always_inline)) { return in_lds ? sp[j] : gpts[j]; };
+  auto rstart = [&](int i) __attribute__((always_inline)) { return in_lds ? sr[i] : grs[i]; };
+  float h0d, h1d, h2d, h3d, r2;
+  int h0i = 0, h1i = 1, h2i = 2, h3i = 3;
+  h0d = sqrtf(fmaxf(dist2(point(0)), 0.f)); h1d = sqrtf(fmaxf(dist2(point(1)), 0.f));
+  h2d = sqrtf(fmaxf(dist2(point(2)), 0.f)); h3d = sqrtf(fmaxf(dist2(point(3)), 0.f));
+  if (!(h3d < h1d)) { const float td = h1d; const int ti = h1i; HE_MOVE(h1, h3); HE_SET(h3, td, ti); }     // __make_heap
+  { const float xd = h0d; const int xi = h0i; HEAP4_REPLACE_ROOT(xd, xi); }
+  r2 = h0d * h0d * 1.000001f + 1e-30f;
+  for (int f = 0; f < T; ++f) {
+    // frames / rows that cannot hold a point below this lane's CURRENT root (same bounds and slack as reach() in idw_knn_kernel)
+    const float r2w = r2 + 2e-6f, dzf = fabsf(qz - gz[f]) - 1e-6f;
+    const float dz2 = dzf > 0.f ? dzf * dzf : 0.f;
+    int lo = 0, hi = 0;
+    if (dz2 <= r2w) {
+      const float ry = sqrtf(r2w - dz2);
+      int kk = ry < 2.f ? (int)(ry * (float)max(H - 1, 1)) + 2 : H;
+      if (kk > H) kk = H;
+      lo = max(rstart(f * (H + 1) + max(0, y - kk)), 4);       // points 0..3 seeded the heap
+      hi = rstart(f * (H + 1) + min(H, y + kk + 1));
+    }
+    // eight points per trip, their reads in flight together (one read per trip is one exposed LDS latency per point: 300 us)
+    int j = lo;
+    for (; j + 8 <= hi; j += 8) {
+      float c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = dist2(point(j + u));
+      const float m = fminf(fminf(fminf(c[0], c[1]), fminf(c[2], c[3])), fminf(fminf(c[4], c[5]), fminf(c[6], c[7])));
+      if (m < r2) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) IDW_CONSIDER_HEAP(c[u], j + u);
+      }
+    }
+    for (; j < hi; ++j) {
+      const float c2 = dist2(point(j));
+      IDW_CONSIDER_HEAP(c2, j);
+    }
+  }
+  IDW_SORT_HEAP();
+  const size_t qo = (size_t)b * Q + q;
+  const float i0 = __fdiv_rn(1.f, h0d + tau), i1 = __fdiv_rn(1.f, h1d + tau);
+  const float i2 = __fdiv_rn(1.f, h2d + tau), i3 = __fdiv_rn(1.f, h3d + tau);
+  float w0 = i0 * i0, w1 = i1 * i1, w2 = i2 * i2, w3 = i3 * i3;
+  const float ws = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(w0, w1), w2), w3), 1e-12f);
+  w0 = __fdiv_rn(w0, ws); w1 = __fdiv_rn(w1, ws); w2 = __fdiv_rn(w2, ws); w3 = __fdiv_rn(w3, ws);
+  const int32_t* pp = pt_pos + (size_t)b * Q;
+  const float* vb = vals + (size_t)b * Q;
+  const float v0 = vb[pp[h0i]], v1 = vb[pp[h1i]], v2 = vb[pp[h2i]], v3 = vb[pp[h3i]];
+  out[qo] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(v0, w0), __fmul_rn(v1, w1)), __fmul_rn(v2, w2)), __fmul_rn(v3, w3));
+  if (sel_idx) {
+    *reinterpret_cast<int4*>(sel_idx + qo * 4) = make_int4(h0i, h1i, h2i, h3i);
+    *reinterpret_cast<float4*>(sel_w + qo * 4) = make_float4(w0, w1, w2, w3);
+  }
+  }
+}
 
 // counts of undecided voxels per MODE-1 workgroup -> exclusive prefix sums, in place (one workgroup per sample)
 __global__ __launch_bounds__(256) void idw_prefix_kernel(int32_t* amb, int Q, int nblk1) {
@@ -479,19 +681,36 @@ static int idw_fwd_impl(const float* vals_src, const float* mask, const float* g
   const dim3 grid(ceil_div(Q, 256), B);
   const int nblk1 = (int)grid.x;
   const float4* pts = reinterpret_cast<const float4*>(pt_xyzn);
+  // P2I_IDW_REPLAY_ALL=1: MODE 2 replays the reference's scan for every listed voxel (round 3's pass) instead of deciding from the
+  // points within the 4th distance first (read per call: A/B runs, tests)
+  const char* rae = getenv("P2I_IDW_REPLAY_ALL");
+  const int replay_all = (rae && atoi(rae) != 0) ? 1 : 0;
   if (amb && nblk1 <= IDW_MAX_BLK) {
     hipLaunchKernelGGL((idw_knn_kernel<1, 256>), grid, dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos, pt_count, row_start, pts, out,
-                       sel_idx, sel_w, amb, nblk1, T, H, W, tau);
+                       sel_idx, sel_w, amb, nblk1, T, H, W, tau, 0);
     hipLaunchKernelGGL(idw_prefix_kernel, dim3(B), dim3(256), 0, s, amb, Q, nblk1);
     // (the number of undecided voxels is known on the device only: a full grid whose surplus workgroups leave at once)
     // 256-thread replay workgroups: 288 us for 8 x 21 k voxels (79 gauges, B = 8); one wave per workgroup (4 x as many windows to
     // load, nothing to overlap them with): 656 us.  Either way the pass is a latency-bound chain per wave (sqrt + heap moves per
     // point some lane takes: ~500 cycles), with 2-3 waves per SIMD in all -- not an instruction-issue limit.
     hipLaunchKernelGGL((idw_knn_kernel<2, 256>), grid, dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos, pt_count,
-                       row_start, pts, out, sel_idx, sel_w, amb, nblk1, T, H, W, tau);
+                       row_start, pts, out, sel_idx, sel_w, amb, nblk1, T, H, W, tau, replay_all);
+    if (!replay_all) {   // what the fixed bound could not decide (~5 % of the listed voxels): the exact replay, a lane per voxel
+      const char* we = getenv("P2I_IDW_LANE_REPLAY");               // 0: the cooperative replay over the second list (A/B; read per call)
+      if (we && atoi(we) == 0)
+        hipLaunchKernelGGL((idw_knn_kernel<2, 256>), grid, dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos, pt_count,
+                           row_start, pts, out, sel_idx, sel_w, amb, nblk1, T, H, W, tau, 3);
+      else {
+        // (the number of voxels left is known on the device only: a full grid whose surplus one-wave workgroups leave at once)
+        const size_t lds = sizeof(float4) * IDW_RW_PCAP + sizeof(int) * (size_t)T * (H + 1);
+        const int use_lds = lds <= 64 * 1024 ? 1 : 0;
+        hipLaunchKernelGGL(idw_replay_lane_kernel, dim3(ceil_div(Q, 64 * 8), B), dim3(64), use_lds ? lds : 0, s, vals_src, grid_x, grid_y, grid_z,
+                           pt_pos, pt_count, row_start, pts, out, sel_idx, sel_w, amb, nblk1, T, H, W, tau, use_lds);
+      }
+    }
   } else {
     hipLaunchKernelGGL((idw_knn_kernel<0, 256>), grid, dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos, pt_count, row_start, pts, out,
-                       sel_idx, sel_w, (int32_t*)nullptr, nblk1, T, H, W, tau);
+                       sel_idx, sel_w, (int32_t*)nullptr, nblk1, T, H, W, tau, 0);
   }
   return launch_status();
 }

@@ -768,6 +768,13 @@ def _idw_strict(pt_count):
             raise RuntimeError("selected index k out of range (idw_3d_knn needs at least 4 mask points per sample, got %s)" % n.tolist())
 
 
+def idw_amb_counts(amb, B, Q):
+    """(voxels per sample that pass 1 left to pass 2, voxels per sample that pass 2's fixed-bound phase left to the exact replay) of
+    the work buffer ops.idw_fwd(..., _amb_out=[...]) hands out (tests, tools)."""
+    per = Q + 1 + (Q + 255) // 256
+    return amb[:B * per].view(B, per)[:, 0].cpu(), amb[B * per:B * per + B * (Q + 1)].view(B, Q + 1)[:, 0].cpu()
+
+
 def idw_fwd(vals_src, mask, tau=0.05, save=True, _amb_out=None):
     """vals_src, mask: (B,T,H,W).  Returns out and the saved selection (pt_pos, sel_idx, sel_w)."""
     lib = _hip.load()
@@ -787,7 +794,7 @@ def idw_fwd(vals_src, mask, tau=0.05, save=True, _amb_out=None):
     sel_w = torch.empty(B * Q * 4, device=dev, dtype=torch.float32) if save else None
     _chk(vals_src, mask)
     if _os.environ.get("P2I_IDW_FAST", "1") != "0":     # two-pass search (p2i_hip.h); "0": the reference's scan for every voxel (A/B, tests)
-        amb = torch.empty(B * (Q + 1 + (Q + 255) // 256), device=dev, dtype=torch.int32)
+        amb = torch.empty(B * (2 * Q + 2 + (Q + 255) // 256), device=dev, dtype=torch.int32)
         _hip.check(lib.p2i_idw_fwd_ws(_ptr(vals_src), _ptr(mask), _ptr(gx), _ptr(gy), _ptr(gz), _ptr(out), _ptr(pt_pos), _ptr(pt_count),
                                       _ptr(frame_count), _ptr(row_start), _ptr(pt_xyzn), _ptr(sel_idx), _ptr(sel_w), _ptr(amb), B, T, H, W,
                                       float(tau), _stream()), "p2i_idw_fwd_ws")

@@ -388,7 +388,17 @@ def test_idw_two_pass_search_equals_index_order_scan(ops, monkeypatch, kind, sha
     mk = mk.cuda()
     amb = []
     out, (pt_pos, pt_count, sel, selw) = ops.idw_fwd(src, mk, _amb_out=amb)
-    counts = amb[0].view(B, -1)[:, 0].cpu()
+    counts, replayed = ops.idw_amb_counts(amb[0], B, T * H * W)
+    assert bool((replayed <= counts).all())
+    if kind in ("gauge", "block") and H * W >= 1024:
+        assert int(replayed.max()) * 4 < int(counts.max()), (counts, replayed)   # the fixed-bound phase decides most listed voxels
+    # round 3's replay pass (every listed voxel through the reference's heap scan) against round 4's decision from the points within
+    # the 4th distance: the same selection sets
+    monkeypatch.setenv("P2I_IDW_REPLAY_ALL", "1")
+    out_r, (_, _, sel_r, _) = ops.idw_fwd(src, mk)
+    monkeypatch.delenv("P2I_IDW_REPLAY_ALL")
+    assert torch.equal(sel.view(-1, 4).sort(dim=1).values, sel_r.view(-1, 4).sort(dim=1).values)
+    assert float((out - out_r).abs().max()) <= 4e-7 * float(out_r.abs().max())
     monkeypatch.setenv("P2I_IDW_FAST", "0")
     out0, (pt_pos0, pt_count0, sel0, selw0) = ops.idw_fwd(src, mk)
     assert torch.equal(pt_pos[: int(pt_count[0])], pt_pos0[: int(pt_count0[0])]) and torch.equal(pt_count, pt_count0)
@@ -424,7 +434,8 @@ def test_idw_dense_mask_matches_oracle(ops, H, block, bwd):
     e = (og.cpu() - ref.detach()).abs()
     bad = int((e > 1e-5 * float(ref.detach().abs().max())).sum())
     assert bad == 0, f"{bad} voxels differ from the oracle"
-    assert 0 < int(amb[0][0]) < T * H * W // 2                      # the replay pass had rank-4/5 ties to decide
+    listed, replayed = ops.idw_amb_counts(amb[0], 1, T * H * W)
+    assert 0 < int(listed[0]) < T * H * W // 2 and int(replayed[0]) <= int(listed[0])      # pass 2 had rank-4/5 ties to decide
     if bwd:
         gout = _rand(1, T, H, W, seed=4)
         ref.backward(gout)

@@ -18,5 +18,6 @@ for name, m in (("gauge79", seeded.gauge_mask(128, 128, 79)), ("block10", seeded
     e1.record(); torch.cuda.synchronize()
     amb = []
     ops.idw_fwd(x, mm, _amb_out=amb)
-    und = ("  undecided voxels/sample (replay pass): %s of %d" % (amb[0].view(B, -1)[:, 0].tolist(), 16 * 128 * 128)) if amb else ""
+    c1, c2 = ops.idw_amb_counts(amb[0], B, 16 * 128 * 128)
+    und = "  listed for pass 2 / left to the exact replay, sample 0: %d / %d of %d voxels" % (int(c1[0]), int(c2[0]), 16 * 128 * 128)
     print(f"B={B} {name}: {e0.elapsed_time(e1) * 100:.1f} us  checksum {float(out.double().sum()):.6f}{und}", flush=True)
