@@ -322,7 +322,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--graph", choices=("on", "off"), default="off",
+    ap.add_argument("--graph", choices=("on", "off", "tape"), default="off",
                     help="replay the whole G+D step as one hipGraph (single GPU).  Off by default: at B=8 the step is bound by "
                          "kernel time, not by dispatch gaps (28.6 ms replayed vs 28.8 ms eager, profiles/README.md)")
     ap.add_argument("--no-stack", action="store_true", help="skip the B=32 generator conv-stack figure (roofline_b32_stack)")
@@ -375,12 +375,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = args.graph == "on"
+    use_graph = args.graph in ("on", "tape")
     done = 0
     if use_graph and world == 1 and args.warmup >= 1:
         # the capture's own eager steps are real training steps and count as warm-up; the timed steps are replays of the
         # captured step (same kernels, same arguments, inputs copied into the captured buffers every step)
-        done = eng.capture(frames, masked, masks, warmup=min(3, args.warmup))
+        done = eng.capture(frames, masked, masks, warmup=min(3, args.warmup), mode="tape" if args.graph == "tape" else "graph")
     for _ in range(max(0, args.warmup - done)):
         eng.train_step(frames, masked, masks)
     sync()
@@ -532,7 +532,8 @@ def main():
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "configs[1]: p2igan_gan_baseline train step, hinge GAN, B=%d per GPU, T=16, 128x128, 79 gauge points/frame" % B,
                            "global_batch": B * world, "parallelism": "dp%d" % world,
-                           "launch": "hipGraph replay of the whole step" if getattr(eng, "_graph", None) is not None else "eager launches"},
+                           "launch": ("launch tape replay of the whole step (p2i_tape_replay)" if getattr(eng, "_tape", None) is not None else
+                                      "hipGraph replay of the whole step") if getattr(eng, "_graph", None) is not None else "eager launches"},
                 "step_tflops": round(GFLOP_PER_SAMPLE_STEP * B * world / (ms_per_step * 1e-3) / 1e3, 2),
                 "roofline": roofline, "cpu_baseline": cpu}
         if rccl is not None:

@@ -327,6 +327,30 @@ int p2i_bias_grad(const float* dy, const float* y_act, int act, float* db, int B
 /* both in one pass: out = dy * act'(y) and db[c] += its sum over samples and positions (db zeroed by the caller; inner % 4 == 0) */
 int p2i_act_bwd_bias(const float* dy, const float* y, int act, float* out, float* db, int B, int C, int64_t inner, void* stream);
 
+/* ---- Native step sequencer: launch tapes (round 4).
+ * Replaces the per-launch host work of the reference's step and inference loops -- scripts/train.py:240-326 (one G+D iteration),
+ * scripts/infer.py:217-241 (one window batch) -- which on this build is ~400 kernel launches + ~400 other calls issued one by one
+ * through the binding (7.1 ms of host time per step, whatever the batch).  Between p2i_tape_begin and p2i_tape_end every kernel
+ * launch, memset and stream dependency this library enqueues ON THE CALLING THREAD is also appended to a tape (the calls execute as
+ * usual, or are captured if the stream is capturing); p2i_tape_replay re-enqueues the recorded operations with the recorded
+ * arguments in one call.  Rules:
+ *   - the tape holds HOST memory only (opaque handle, freed by p2i_tape_free); every device buffer it names is the caller's and
+ *     must still be alive, at the same address, when it is replayed (the Python engine records inside a private memory pool);
+ *   - operations recorded on `origin_stream` are replayed on the origin stream given to p2i_tape_replay (the caller's current
+ *     stream); operations on other streams (side streams) are replayed on those same streams;
+ *   - cross-stream dependencies must be expressed through p2i_event_record / p2i_event_wait (slots 0..255 of a per-thread table
+ *     of events without timing) to be seen by a tape; enqueue-only like everything else, no synchronisation;
+ *   - host-side values baked into kernel arguments are replayed as recorded (use p2i_adam_dev, whose step counter lives on the
+ *     device). */
+int p2i_event_record(int slot, void* stream);
+int p2i_event_wait(int slot, void* stream);
+int p2i_tape_begin(void* origin_stream);
+int p2i_tape_end(void** tape_out);
+/* counts4: kernels, memsets, event operations, distinct streams */
+int p2i_tape_info(const void* tape, int* counts4);
+int p2i_tape_replay(const void* tape, void* origin_stream);
+int p2i_tape_free(void* tape);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "p2i_hip.h"
+#include "tape.h"
 
 namespace p2i {
 

@@ -124,7 +124,7 @@ int c1_dgrad(const p2i_conv_desc* d, const float* dy, const float* wp_d, const f
   const int ntaps = d->kt * d->kh * d->kw;
   const size_t total = (size_t)d->B * d->Ti * d->Hi * d->Wi;
   const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  hipLaunchKernelGGL(c1_dgrad_kernel, dim3(grid), dim3(256), sizeof(float) * ntaps * d->Cout, s, *d, dy, wp_d, add, mask_y, mask_act, dx);
+  P2I_LAUNCH(c1_dgrad_kernel, dim3(grid), dim3(256), sizeof(float) * ntaps * d->Cout, s, *d, dy, wp_d, add, mask_y, mask_act, dx);
   return launch_status();
 }
 
@@ -139,7 +139,7 @@ int c1_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp
   const int eW = (NPW - 1) * d->sw + d->kw, eH = d->sh + d->kh;
   const size_t lds = sizeof(float) * ((size_t)d->kt * eH * eW + (size_t)d->Cout * (2 * NPW + 1));
   const int grid = ntiles < 1024 ? ntiles : 1024;
-  hipLaunchKernelGGL(c1_wgrad_kernel<NPW>, dim3(grid), dim3(256), lds, s, *d, x, dy, dwp, dbias, ntw, ntiles);
+  P2I_LAUNCH(c1_wgrad_kernel<NPW>, dim3(grid), dim3(256), lds, s, *d, x, dy, dwp, dbias, ntw, ntiles);
   return launch_status();
 }
 
@@ -465,7 +465,7 @@ int c1_fwd(const p2i_conv_desc* d, const float* x, const float* wp, const float*
   const long long ntiles = (long long)d->B * d->To * nth * ntw;
   if (ntiles > 0x7fffffff) return 1;
   const int grid = (int)ntiles;                               // (the kernel loops; > 1 tile per workgroup measured slower)
-  hipLaunchKernelGGL(c1_fwd_kernel, dim3(grid), dim3(256), 0, s, *d, x, wp, bias, y, act, nth, ntw, (int)ntiles);
+  P2I_LAUNCH(c1_fwd_kernel, dim3(grid), dim3(256), 0, s, *d, x, wp, bias, y, act, nth, ntw, (int)ntiles);
   return launch_status();
 }
 
@@ -474,7 +474,7 @@ static int c1_dgrad_fast(const p2i_conv_desc* d, const float* dy, const float* w
   const int nJ = (d->Wi + 1) / 2, nI = (d->Hi + 1) / 2, nTB = (d->Ti + 3) / 4;
   const long long nthr = (long long)d->B * nTB * nI * nJ;
   if ((long long)d->To * d->Ho * d->Wo >= (1ll << 31)) return 1;
-  hipLaunchKernelGGL(c1_dgrad_fast_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, *d, dy, wp_d, add, mask_y, mask_act, dx,
+  P2I_LAUNCH(c1_dgrad_fast_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, *d, dy, wp_d, add, mask_y, mask_act, dx,
                      nJ, nI, nTB);
   return launch_status();
 }
@@ -491,7 +491,7 @@ static int c1_wgrad_mfma(const p2i_conv_desc* d, const float* x, const float* dy
     attr_set = true;
   }
   const int grid = ntiles < 512 ? (int)ntiles : 512;
-  hipLaunchKernelGGL(c1_wgrad_mfma_kernel, dim3(grid), dim3(256), lds, s, *d, x, dy, dwp, dbias, nth, ntw, (int)ntiles);
+  P2I_LAUNCH(c1_wgrad_mfma_kernel, dim3(grid), dim3(256), lds, s, *d, x, dy, dwp, dbias, nth, ntw, (int)ntiles);
   return launch_status();
 }
 
@@ -598,7 +598,7 @@ int o1_fwd(const p2i_conv_desc* d, const float* x, const float* wp, const float*
   const long long nt = (long long)d->B * nth * ntw;
   if (nt > 0x7fffffff) return 1;
   const size_t lds = sizeof(float) * (size_t)(((d->Cin * 9 + 63) & ~63) + 8 * 64);
-  hipLaunchKernelGGL(o1_fwd_kernel, dim3((unsigned)nt), dim3(512), lds, s, x, wp, bias, y, d->Cin, d->Hi, d->Wi, nth, ntw, act);
+  P2I_LAUNCH(o1_fwd_kernel, dim3((unsigned)nt), dim3(512), lds, s, x, wp, bias, y, d->Cin, d->Hi, d->Wi, nth, ntw, act);
   return launch_status();
 }
 

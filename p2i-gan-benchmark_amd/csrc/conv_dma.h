@@ -366,7 +366,7 @@ static inline int launch_patch_dma_nt(const PatchGeom& g, dim3 grid, size_t lds,
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k, grid, dim3(256 * KG), lds, s, g);
+  P2I_LAUNCH(k, grid, dim3(256 * KG), lds, s, g);
   return launch_status();
 }
 template <int MB, int NPIX, int WM, int CK, int KG>

@@ -291,7 +291,7 @@ static int launch_fused(const PatchGeom& g, dim3 grid, size_t lds, hipStream_t s
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, g);
+  P2I_LAUNCH(k, grid, dim3(256), lds, s, g);
   return launch_status();
 }
 

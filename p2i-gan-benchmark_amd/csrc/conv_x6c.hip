@@ -99,7 +99,7 @@ X6Ctx& x6_ctx() {
 int x6_split_weights(const float* wp, uint16_t* wb, int ntaps, int Ck, int CmPad, hipStream_t s) {
   const int total = ntaps * (Ck >> 3) * CmPad;
   const int blocks = total > 0 ? (total + 255) / 256 : 1;
-  hipLaunchKernelGGL(wsplit_kernel, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, s, wp, reinterpret_cast<u32x4c*>(wb), ntaps, Ck, CmPad);
+  P2I_LAUNCH(wsplit_kernel, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, s, wp, reinterpret_cast<u32x4c*>(wb), ntaps, Ck, CmPad);
   return launch_status();
 }
 
@@ -1291,7 +1291,7 @@ static void x6c_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)patch_gemm_x6c_kernel<NW, TM, FUSED, TPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((patch_gemm_x6c_kernel<NW, TM, FUSED, TPS>), grid, dim3(64 * NW), lds, s, g);
+  P2I_LAUNCH((patch_gemm_x6c_kernel<NW, TM, FUSED, TPS>), grid, dim3(64 * NW), lds, s, g);
 }
 template <int TM, int TPS, bool FUSED = false, bool EPI4 = false, int NPW = 4, int TN = 2>
 static void x6p_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
@@ -1300,7 +1300,7 @@ static void x6p_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW, TN>), grid, dim3(64 * (4 + NPW)), lds, s, g);
+  P2I_LAUNCH((patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW, TN>), grid, dim3(64 * (4 + NPW)), lds, s, g);
 }
 // P2I_X6P_NPW=4: one producer wave per SIMD for the 32-channel tiles too (default 8); read per call (A/B runs)
 static int x6p_npw() { const char* e = getenv("P2I_X6P_NPW"); return (e && atoi(e) == 4) ? 4 : 8; }
@@ -1380,7 +1380,7 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   const int post_act = (pk.ksplit > 1 && g.act_epi != P2I_ACT_NONE) ? g.act_epi : P2I_ACT_NONE;
   const float* post_res = nullptr;
   if (pk.ksplit > 1) {       // partial sums are added: start from zero (stream-ordered in front of the kernel)
-    if (hipMemsetAsync(g.dst, 0, sizeof(float) * (size_t)n_dst, s) != hipSuccess) return P2I_EINVAL;
+    if (p2i::memset_async(g.dst, 0, sizeof(float) * (size_t)n_dst, s) != hipSuccess) return P2I_EINVAL;
     if (post_act != P2I_ACT_NONE) { post_res = g.res; g.res = nullptr; g.act_epi = P2I_ACT_NONE; }   // act(sum + bias) + res: second pass
   }
   if (plan6) { plan6[0] = 32 * tv.TM; plan6[1] = 32 * tv.NW; plan6[2] = pk.ksplit; plan6[3] = (x6c_pc() && g.Ck >= 32) ? 4 : 8; plan6[4] = tps; plan6[5] = 7; }
@@ -1417,7 +1417,7 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   if (post_act != P2I_ACT_NONE) {
     const long long n4 = n_dst / 4;
     const long long blocks = (n4 + 255) / 256;
-    hipLaunchKernelGGL(x6c_post_act_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, g.dst, post_res, n4, post_act);
+    P2I_LAUNCH(x6c_post_act_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, g.dst, post_res, n4, post_act);
   }
   return launch_status();
 }
@@ -1495,7 +1495,7 @@ int run_patch_gemm_x6c_fused(PatchGeom g, const ClassSpec* css, int ncls, const 
     const ClassSpec& c = css[slot_cls[sl]];
     k.tap_off[sl] = c.dh[slot_idx[sl]] * k.eW + c.dw[slot_idx[sl]];
   }
-  if (ksplit > 1 && hipMemsetAsync(g.dst, 0, sizeof(float) * (size_t)n_dst, s) != hipSuccess) return P2I_EINVAL;
+  if (ksplit > 1 && p2i::memset_async(g.dst, 0, sizeof(float) * (size_t)n_dst, s) != hipSuccess) return P2I_EINVAL;
   const dim3 grid((unsigned)(ceil_div((int)nimg, jb) * k.nth * k.ntw), (unsigned)ceil_div(g.Cm, 32), (unsigned)ksplit);
   const int tps = x6c_tps1();
   const size_t lds = x6c_lds_bytes(k.CSl, 1, tps);
@@ -1521,6 +1521,6 @@ extern "C" int p2i_x6_split_batched(const float* const* wp, uint16_t* const* wb,
     if (tot > maxn) maxn = tot;
   }
   const int blocks = (maxn + 255) / 256;
-  hipLaunchKernelGGL(wsplit_batched_kernel, dim3(blocks > 1024 ? 1024 : blocks, n), dim3(256), 0, (hipStream_t)stream, b);
+  P2I_LAUNCH(wsplit_batched_kernel, dim3(blocks > 1024 ? 1024 : blocks, n), dim3(256), 0, (hipStream_t)stream, b);
   return launch_status();
 }

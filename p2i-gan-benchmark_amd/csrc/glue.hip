@@ -489,9 +489,9 @@ extern "C" int p2i_attn_fwd(const float* x, const float* w0, const float* b0, co
   P2I_REQUIRE(T == 8 || T == 16 || T == 32, "AttentionBlock kernels exist for T in {8, 16, 32}");
   const dim3 grid(ceil_div(HW, 256), B);
   hipStream_t s = (hipStream_t)stream;
-  if (T == 16) hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, out, B, HW);
-  else if (T == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, out, B, HW);
-  else hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, out, B, HW);
+  if (T == 16) P2I_LAUNCH(attn_fwd_kernel<16>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, out, B, HW);
+  else if (T == 32) P2I_LAUNCH(attn_fwd_kernel<32>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, out, B, HW);
+  else P2I_LAUNCH(attn_fwd_kernel<8>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, out, B, HW);
   return launch_status();
 }
 extern "C" int p2i_attn_bwd(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
@@ -500,23 +500,23 @@ extern "C" int p2i_attn_bwd(const float* x, const float* w0, const float* b0, co
   P2I_REQUIRE(T == 8 || T == 16 || T == 32, "AttentionBlock kernels exist for T in {8, 16, 32}");
   const dim3 grid(ceil_div(HW, 256), B);
   hipStream_t s = (hipStream_t)stream;
-  if (T == 16) hipLaunchKernelGGL(attn_bwd_kernel<16>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW);
-  else if (T == 32) hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW);
-  else hipLaunchKernelGGL(attn_bwd_kernel<8>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW);
+  if (T == 16) P2I_LAUNCH(attn_bwd_kernel<16>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW);
+  else if (T == 32) P2I_LAUNCH(attn_bwd_kernel<32>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW);
+  else P2I_LAUNCH(attn_bwd_kernel<8>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW);
   return launch_status();
 }
 extern "C" int p2i_pooldup_fwd(const float* x, float* y, int B, int C, int H, int W, void* stream) {
   P2I_REQUIRE(x && y, "null pointer");
   P2I_REQUIRE(H % 2 == 0 && W % 2 == 0, "pooldup needs even H, W");
   const int64_t n = (int64_t)B * C * (H / 2) * (W / 2);
-  hipLaunchKernelGGL(pooldup_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, B * C, H, W);
+  P2I_LAUNCH(pooldup_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, B * C, H, W);
   return launch_status();
 }
 extern "C" int p2i_pooldup_bwd(const float* x, const float* dy, float* dx, int B, int C, int H, int W, void* stream) {
   P2I_REQUIRE(x && dy && dx, "null pointer");
   P2I_REQUIRE(H % 2 == 0 && W % 2 == 0, "pooldup needs even H, W");
   const int64_t n = (int64_t)B * C * (H / 2) * (W / 2);
-  hipLaunchKernelGGL(pooldup_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, B * C, H, W);
+  P2I_LAUNCH(pooldup_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, B * C, H, W);
   return launch_status();
 }
 extern "C" int p2i_upmod_fwd(const float* x, const float* pos, float* u, int B, int C, int S, int S2w, void* stream) {
@@ -525,7 +525,7 @@ extern "C" int p2i_upmod_fwd(const float* x, const float* pos, float* u, int B, 
     const int BC = B * C, npix = 4 * S * S2w;
     int chunk = BC;                                  // enough (pixel tile, channel chunk) blocks to fill the chip ~8 times
     while (chunk > 8 && (long long)ceil_div(npix, 256) * ceil_div(BC, chunk) < 2048) chunk = (chunk + 1) / 2;
-    hipLaunchKernelGGL(upmod_fwd_kernel, dim3(ceil_div(npix, 256), ceil_div(BC, chunk)), dim3(256), 0, (hipStream_t)stream, x, pos, u, BC, S, S2w, chunk,
+    P2I_LAUNCH(upmod_fwd_kernel, dim3(ceil_div(npix, 256), ceil_div(BC, chunk)), dim3(256), 0, (hipStream_t)stream, x, pos, u, BC, S, S2w, chunk,
                        (const float*)nullptr, P2I_ACT_NONE, C);
   }
   return launch_status();
@@ -535,7 +535,7 @@ extern "C" int p2i_upmod_fwd_ba(const float* x, const float* pos, const float* b
   const int BC = B * C, npix = 4 * S * S2w;
   int chunk = BC;
   while (chunk > 8 && (long long)ceil_div(npix, 256) * ceil_div(BC, chunk) < 2048) chunk = (chunk + 1) / 2;
-  hipLaunchKernelGGL(upmod_fwd_kernel, dim3(ceil_div(npix, 256), ceil_div(BC, chunk)), dim3(256), 0, (hipStream_t)stream, x, pos, u, BC, S, S2w, chunk,
+  P2I_LAUNCH(upmod_fwd_kernel, dim3(ceil_div(npix, 256), ceil_div(BC, chunk)), dim3(256), 0, (hipStream_t)stream, x, pos, u, BC, S, S2w, chunk,
                      bias, act, C);
   return launch_status();
 }
@@ -546,7 +546,7 @@ extern "C" int p2i_upmod_bwd(const float* x, const float* pos, const float* du, 
   const int BC = B * C;
   if (dpos) {
     const int chunk = 16;
-    hipLaunchKernelGGL(upmod_bwd_pos_kernel, dim3(ceil_div(4 * S * S2w, 256), ceil_div(BC, chunk)), dim3(256), 0, s, x, pos, du, dpos,
+    P2I_LAUNCH(upmod_bwd_pos_kernel, dim3(ceil_div(4 * S * S2w, 256), ceil_div(BC, chunk)), dim3(256), 0, s, x, pos, du, dpos,
                        BC, S, S2w, chunk);
   }
   if (dx) {
@@ -554,7 +554,7 @@ extern "C" int p2i_upmod_bwd(const float* x, const float* pos, const float* du, 
       const int npin = S * S2w;
       int chunk2 = BC;
       while (chunk2 > 8 && (long long)ceil_div(npin, 256) * ceil_div(BC, chunk2) < 2048) chunk2 = (chunk2 + 1) / 2;
-      hipLaunchKernelGGL(upmod_bwd_x_kernel, dim3(ceil_div(npin, 256), ceil_div(BC, chunk2)), dim3(256), 0, s, pos, du, dx, BC, S, S2w, chunk2);
+      P2I_LAUNCH(upmod_bwd_x_kernel, dim3(ceil_div(npin, 256), ceil_div(BC, chunk2)), dim3(256), 0, s, pos, du, dx, BC, S, S2w, chunk2);
     }
   }
   return launch_status();
@@ -562,7 +562,7 @@ extern "C" int p2i_upmod_bwd(const float* x, const float* pos, const float* du, 
 extern "C" int p2i_dtail_fwd(const float* out2d, const float* out3d, const float* alpha2d, float* fused, int B, int H2, int W2,
                              int T3, int H3, int W3, void* stream) {
   P2I_REQUIRE(out2d && out3d && alpha2d && fused, "null pointer");
-  hipLaunchKernelGGL(dtail_fwd_kernel, dim3(ceil_div(B * H2 * W2, 256)), dim3(256), 0, (hipStream_t)stream, out2d, out3d, alpha2d,
+  P2I_LAUNCH(dtail_fwd_kernel, dim3(ceil_div(B * H2 * W2, 256)), dim3(256), 0, (hipStream_t)stream, out2d, out3d, alpha2d,
                      fused, B, H2, W2, T3, H3, W3);
   return launch_status();
 }
@@ -571,9 +571,9 @@ extern "C" int p2i_dtail_bwd(const float* out2d, const float* alpha2d, const flo
   P2I_REQUIRE(out2d && alpha2d && dfused, "null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int n = B * H2 * W2;
-  hipLaunchKernelGGL(dtail_bwd2_kernel, dim3(min(ceil_div(n, 256), 64)), dim3(256), 0, s, out2d, alpha2d, dfused, dout2d, dalpha2d, n);
+  P2I_LAUNCH(dtail_bwd2_kernel, dim3(min(ceil_div(n, 256), 64)), dim3(256), 0, s, out2d, alpha2d, dfused, dout2d, dalpha2d, n);
   if (dout3d)
-    hipLaunchKernelGGL(dtail_bwd3_kernel, dim3(ceil_div(B * H3 * W3, 256)), dim3(256), 0, s, dfused, dout3d, B, H2, W2, T3, H3, W3);
+    P2I_LAUNCH(dtail_bwd3_kernel, dim3(ceil_div(B * H3 * W3, 256)), dim3(256), 0, s, dfused, dout3d, B, H2, W2, T3, H3, W3);
   return launch_status();
 }
 extern "C" int p2i_bias_grad(const float* dy, const float* y_act, int act, float* db, int B, int C, int64_t inner, void* stream) {
@@ -582,12 +582,12 @@ extern "C" int p2i_bias_grad(const float* dy, const float* y_act, int act, float
   int chunks = (int)((total + 16383) / 16384);
   if (chunks > 64) chunks = 64;
   if (chunks < 1) chunks = 1;
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dy, y_act, act, db, B, C, inner);
+  P2I_LAUNCH(bias_grad_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dy, y_act, act, db, B, C, inner);
   return launch_status();
 }
 extern "C" int p2i_act_bwd(const float* dy, const float* y, int act, float* out, int64_t n, void* stream) {
   P2I_REQUIRE(dy && y && out && n > 0, "null pointer");
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dy, y, act, out, n / 4, n);
+  P2I_LAUNCH(act_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dy, y, act, out, n / 4, n);
   return launch_status();
 }
 extern "C" int p2i_act_bwd_bias(const float* dy, const float* y, int act, float* out, float* db, int B, int C, int64_t inner, void* stream) {
@@ -595,31 +595,31 @@ extern "C" int p2i_act_bwd_bias(const float* dy, const float* y, int act, float*
   P2I_REQUIRE((inner & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) & 15) == 0, "inner % 4 and 16-byte alignment");
   int chunks = (int)((inner / 4 + 2047) / 2048);
   if (chunks > 16) chunks = 16;
-  hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(C, B, chunks), dim3(256), 0, (hipStream_t)stream, dy, y, act, out, db, C, inner / 4);
+  P2I_LAUNCH(act_bwd_bias_kernel, dim3(C, B, chunks), dim3(256), 0, (hipStream_t)stream, dy, y, act, out, db, C, inner / 4);
   return launch_status();
 }
 extern "C" int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stream) {
   P2I_REQUIRE(y && x, "null pointer");
-  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, x, a, n);
+  P2I_LAUNCH(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, x, a, n);
   return launch_status();
 }
 extern "C" int p2i_add2(float* out, const float* a, const float* b, int64_t n, void* stream) {
   P2I_REQUIRE(out && a && b && n >= 0, "null pointer");
   const bool al = (((uintptr_t)out | (uintptr_t)a | (uintptr_t)b) & 15) == 0;
   const int64_t n4 = al ? n / 4 : 0;
-  hipLaunchKernelGGL(add2_kernel, dim3(grid_for(n4 + 1)), dim3(256), 0, (hipStream_t)stream, out, a, b, n4, n);
+  P2I_LAUNCH(add2_kernel, dim3(grid_for(n4 + 1)), dim3(256), 0, (hipStream_t)stream, out, a, b, n4, n);
   return launch_status();
 }
 extern "C" int p2i_zero(float* p, int64_t n, void* stream) {
   P2I_REQUIRE(p && n >= 0, "null pointer");
-  if (n > 0 && hipMemsetAsync(p, 0, sizeof(float) * (size_t)n, (hipStream_t)stream) != hipSuccess) { set_error("memset failed"); return P2I_EINVAL; }
+  if (n > 0 && p2i::memset_async(p, 0, sizeof(float) * (size_t)n, (hipStream_t)stream) != hipSuccess) { set_error("memset failed"); return P2I_EINVAL; }
   return P2I_OK;
 }
 extern "C" int p2i_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                         int step, void* stream) {
   P2I_REQUIRE(p && g && m && v && step >= 1, "bad adam arguments");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(lr / bc1), beta1,
+  P2I_LAUNCH(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(lr / bc1), beta1,
                      beta2, eps, (float)sqrt(bc2));
   return launch_status();
 }
@@ -627,8 +627,8 @@ extern "C" int p2i_adam(float* p, const float* g, float* m, float* v, int64_t n,
 extern "C" int p2i_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                             int32_t* step_dev, float* coef2, void* stream) {
   P2I_REQUIRE(p && g && m && v && step_dev && coef2, "bad adam arguments");
-  hipLaunchKernelGGL(adam_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, coef2, lr, beta1, beta2);
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, coef2, beta1, beta2, eps);
+  P2I_LAUNCH(adam_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, coef2, lr, beta1, beta2);
+  P2I_LAUNCH(adam_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, coef2, beta1, beta2, eps);
   return launch_status();
 }
 
@@ -699,7 +699,7 @@ extern "C" int p2i_window_gather(const float* a, const float* b, float* wa, floa
   P2I_REQUIRE(a && wa && (b == nullptr) == (wb == nullptr), "null pointer");
   P2I_REQUIRE(L > 0 && nw > 0 && win > 0 && step > 0 && HW > 0 && (HW & 3) == 0, "bad window geometry (H*W must be a multiple of 4)");
   P2I_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)wa | (uintptr_t)wb) & 15) == 0, "16-byte alignment");
-  hipLaunchKernelGGL(window_gather_kernel, dim3(grid_for((int64_t)nw * win * (HW / 4))), dim3(256), 0, (hipStream_t)stream, a, b, wa, wb, L, HW / 4,
+  P2I_LAUNCH(window_gather_kernel, dim3(grid_for((int64_t)nw * win * (HW / 4))), dim3(256), 0, (hipStream_t)stream, a, b, wa, wb, L, HW / 4,
                      w0, nw, win, step);
   return launch_status();
 }
@@ -707,7 +707,7 @@ extern "C" int p2i_window_mean(const float* pred_windows, float* out, int L, int
   P2I_REQUIRE(pred_windows && out, "null pointer");
   P2I_REQUIRE(L > 0 && nwin > 0 && win > 0 && step > 0 && HW > 0 && (HW & 3) == 0 && (nwin - 1) * step < L, "bad window geometry");
   P2I_REQUIRE((((uintptr_t)pred_windows | (uintptr_t)out) & 15) == 0, "16-byte alignment");
-  hipLaunchKernelGGL(window_mean_kernel, dim3(grid_for((int64_t)L * (HW / 4))), dim3(256), 0, (hipStream_t)stream, pred_windows, out, L, HW / 4, nwin,
+  P2I_LAUNCH(window_mean_kernel, dim3(grid_for((int64_t)L * (HW / 4))), dim3(256), 0, (hipStream_t)stream, pred_windows, out, L, HW / 4, nwin,
                      win, step, scale);
   return launch_status();
 }
@@ -718,7 +718,7 @@ extern "C" int p2i_assemble_batch(const uint8_t* frames_u8, const uint8_t* mask_
   const long long hw = (long long)H * W, n = (long long)B * T * hw;
   P2I_REQUIRE(mask_numel == hw || mask_numel == (long long)T * hw || mask_numel == n, "mask must be (H,W), (T,H,W) or (B,T,H,W)");
   const long long blocks = (n + 1023) / 1024;
-  hipLaunchKernelGGL(p2i::assemble_batch_kernel, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)stream,
+  P2I_LAUNCH(p2i::assemble_batch_kernel, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)stream,
                      frames_u8, mask_u8, frames, masked, masks, n, (long long)mask_numel);
   return p2i::launch_status();
 }

@@ -675,8 +675,8 @@ static int idw_fwd_impl(const float* vals_src, const float* mask, const float* g
   P2I_REQUIRE((long long)B * T * H * W < (1ll << 29), "IDW problem too large");
   hipStream_t s = (hipStream_t)stream;
   const int Q = T * H * W;
-  hipLaunchKernelGGL(idw_count_kernel, dim3(B * T), dim3(IDW_CT), 0, s, mask, frame_count, H * W);
-  hipLaunchKernelGGL(idw_compact_kernel, dim3(B * T), dim3(IDW_CT), 0, s, mask, frame_count, grid_x, grid_y, grid_z, pt_pos, pt_count,
+  P2I_LAUNCH(idw_count_kernel, dim3(B * T), dim3(IDW_CT), 0, s, mask, frame_count, H * W);
+  P2I_LAUNCH(idw_compact_kernel, dim3(B * T), dim3(IDW_CT), 0, s, mask, frame_count, grid_x, grid_y, grid_z, pt_pos, pt_count,
                      row_start, pt_xyzn, amb, T, H, W);
   const dim3 grid(ceil_div(Q, 256), B);
   const int nblk1 = (int)grid.x;
@@ -686,30 +686,30 @@ static int idw_fwd_impl(const float* vals_src, const float* mask, const float* g
   const char* rae = getenv("P2I_IDW_REPLAY_ALL");
   const int replay_all = (rae && atoi(rae) != 0) ? 1 : 0;
   if (amb && nblk1 <= IDW_MAX_BLK) {
-    hipLaunchKernelGGL((idw_knn_kernel<1, 256>), grid, dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos, pt_count, row_start, pts, out,
+    P2I_LAUNCH((idw_knn_kernel<1, 256>), grid, dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos, pt_count, row_start, pts, out,
                        sel_idx, sel_w, amb, nblk1, T, H, W, tau, 0);
-    hipLaunchKernelGGL(idw_prefix_kernel, dim3(B), dim3(256), 0, s, amb, Q, nblk1);
+    P2I_LAUNCH(idw_prefix_kernel, dim3(B), dim3(256), 0, s, amb, Q, nblk1);
     // (the number of undecided voxels is known on the device only: a full grid whose surplus workgroups leave at once)
     // 256-thread replay workgroups: 288 us for 8 x 21 k voxels (79 gauges, B = 8); one wave per workgroup (4 x as many windows to
     // load, nothing to overlap them with): 656 us.  Either way the pass is a latency-bound chain per wave (sqrt + heap moves per
     // point some lane takes: ~500 cycles), with 2-3 waves per SIMD in all -- not an instruction-issue limit.
-    hipLaunchKernelGGL((idw_knn_kernel<2, 256>), grid, dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos, pt_count,
+    P2I_LAUNCH((idw_knn_kernel<2, 256>), grid, dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos, pt_count,
                        row_start, pts, out, sel_idx, sel_w, amb, nblk1, T, H, W, tau, replay_all);
     if (!replay_all) {   // what the fixed bound could not decide (~5 % of the listed voxels): the exact replay, a lane per voxel
       const char* we = getenv("P2I_IDW_LANE_REPLAY");               // 0: the cooperative replay over the second list (A/B; read per call)
       if (we && atoi(we) == 0)
-        hipLaunchKernelGGL((idw_knn_kernel<2, 256>), grid, dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos, pt_count,
+        P2I_LAUNCH((idw_knn_kernel<2, 256>), grid, dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos, pt_count,
                            row_start, pts, out, sel_idx, sel_w, amb, nblk1, T, H, W, tau, 3);
       else {
         // (the number of voxels left is known on the device only: a full grid whose surplus one-wave workgroups leave at once)
         const size_t lds = sizeof(float4) * IDW_RW_PCAP + sizeof(int) * (size_t)T * (H + 1);
         const int use_lds = lds <= 64 * 1024 ? 1 : 0;
-        hipLaunchKernelGGL(idw_replay_lane_kernel, dim3(ceil_div(Q, 64 * 8), B), dim3(64), use_lds ? lds : 0, s, vals_src, grid_x, grid_y, grid_z,
+        P2I_LAUNCH(idw_replay_lane_kernel, dim3(ceil_div(Q, 64 * 8), B), dim3(64), use_lds ? lds : 0, s, vals_src, grid_x, grid_y, grid_z,
                            pt_pos, pt_count, row_start, pts, out, sel_idx, sel_w, amb, nblk1, T, H, W, tau, use_lds);
       }
     }
   } else {
-    hipLaunchKernelGGL((idw_knn_kernel<0, 256>), grid, dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos, pt_count, row_start, pts, out,
+    P2I_LAUNCH((idw_knn_kernel<0, 256>), grid, dim3(256), 0, s, vals_src, grid_x, grid_y, grid_z, pt_pos, pt_count, row_start, pts, out,
                        sel_idx, sel_w, (int32_t*)nullptr, nblk1, T, H, W, tau, 0);
   }
   return launch_status();
@@ -736,9 +736,9 @@ extern "C" int p2i_idw_bwd(const float* dout, const int32_t* pt_pos, const int32
   P2I_REQUIRE(dout && pt_pos && pt_count && sel_idx && sel_w && dvals_src, "null pointer");
   const int Q = T * H * W;
   const size_t total = (size_t)B * Q;
-  (void)hipMemsetAsync(dvals_src, 0, sizeof(float) * total, (hipStream_t)stream);
+  (void)p2i::memset_async(dvals_src, 0, sizeof(float) * total, (hipStream_t)stream);
   const int chunk = 4096;
-  hipLaunchKernelGGL(idw_bwd_kernel, dim3(ceil_div(Q, chunk), B), dim3(256), 0, (hipStream_t)stream, dout, pt_pos, pt_count, sel_idx,
+  P2I_LAUNCH(idw_bwd_kernel, dim3(ceil_div(Q, chunk), B), dim3(256), 0, (hipStream_t)stream, dout, pt_pos, pt_count, sel_idx,
                      sel_w, dvals_src, Q, chunk);
   return launch_status();
 }

@@ -153,9 +153,9 @@ extern "C" int p2i_recloss(const float* pred, const float* target, float k1_alph
   const int nblk = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
   P2I_REQUIRE(nrows + nblk <= 4096, "recloss scratch tail too small (B*(T-1) + blocks <= 4096)");
   // d(k1*reg)/d diff = k1 * (p_hat - q) / (temp * B)
-  hipLaunchKernelGGL(kl_row_kernel, dim3(nrows), dim3(1024), 0, s, pred, target, G, rowkl, T, HW, k1_alpha / (0.1f * (float)B));
-  hipLaunchKernelGGL(l1_grad_kernel, dim3(nblk), dim3(256), 0, s, pred, target, G, dpred, partial, T, HW, total, 1.f / (float)total);
-  hipLaunchKernelGGL(recloss_final_kernel, dim3(1), dim3(256), 0, s, partial, nblk, rowkl, nrows, 1.f / (float)total, 1.f / (float)B,
+  P2I_LAUNCH(kl_row_kernel, dim3(nrows), dim3(1024), 0, s, pred, target, G, rowkl, T, HW, k1_alpha / (0.1f * (float)B));
+  P2I_LAUNCH(l1_grad_kernel, dim3(nblk), dim3(256), 0, s, pred, target, G, dpred, partial, T, HW, total, 1.f / (float)total);
+  P2I_LAUNCH(recloss_final_kernel, dim3(1), dim3(256), 0, s, partial, nblk, rowkl, nrows, 1.f / (float)total, 1.f / (float)B,
                      k1_alpha, out3);
   return launch_status();
 }
@@ -165,7 +165,7 @@ extern "C" int p2i_gan_loss(const float* logits_a, const float* logits_b, int n,
   P2I_REQUIRE(logits_a && loss && n > 0, "null pointer");
   P2I_REQUIRE(loss_type >= 0 && loss_type <= 2, "loss_type: 0 hinge, 1 lsgan, 2 nsgan");
   P2I_REQUIRE(mode == 1 || logits_b, "discriminator mode needs both logit tensors");
-  hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits_a, logits_b, n, loss_type, mode, weight,
+  P2I_LAUNCH(gan_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits_a, logits_b, n, loss_type, mode, weight,
                      real_label, fake_label, loss, dlogits_a, dlogits_b);
   return launch_status();
 }

@@ -143,7 +143,7 @@ extern "C" int p2i_metrics_pointwise(const float* pred, const float* target, int
   MetricArgs a;
   if (int e = fill_args(a, thresholds_host, nt, nullptr, 0, apply_transform)) return e;
   const long long blocks = (n + 256 * 8 - 1) / (256 * 8);
-  hipLaunchKernelGGL(metrics_pointwise_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream,
+  P2I_LAUNCH(metrics_pointwise_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream,
                      pred, target, (long long)n, a, sums2, counts, bits);
   return launch_status();
 }
@@ -156,7 +156,7 @@ extern "C" int p2i_metrics_fss(const uint8_t* bits, int N, int H, int W, int nt,
   if (int e = fill_args(a, dummy, nt, scales_host, ns, 1)) return e;
   const long long total = (long long)N * (H + 1) * (W + 1);
   const long long blocks = (total + 255) / 256;
-  hipLaunchKernelGGL(metrics_fss_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, (hipStream_t)stream, bits, N, H, W,
+  P2I_LAUNCH(metrics_fss_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, (hipStream_t)stream, bits, N, H, W,
                      a, num, den);
   return launch_status();
 }

@@ -510,14 +510,14 @@ extern "C" int p2i_doconv_fold_fwd(const float* W, const float* D, const float* 
   P2I_REQUIRE(ksz == 1 || (D && D_diag), "3x3 DO-Conv needs D and D_diag");
   hipStream_t s = (hipStream_t)stream;
   const int nt = ksz * ksz, Opad = (O + 31) / 32 * 32, Ipad = (I + 31) / 32 * 32;
-  if (groups > 1 || Opad != O) (void)hipMemsetAsync(wp_f, 0, sizeof(float) * (size_t)nt * I * Opad, s);
-  if (wp_d && (groups > 1 || Ipad != I)) (void)hipMemsetAsync(wp_d, 0, sizeof(float) * (size_t)nt * O * Ipad, s);
+  if (groups > 1 || Opad != O) (void)p2i::memset_async(wp_f, 0, sizeof(float) * (size_t)nt * I * Opad, s);
+  if (wp_d && (groups > 1 || Ipad != I)) (void)p2i::memset_async(wp_d, 0, sizeof(float) * (size_t)nt * O * Ipad, s);
   if (ksz == 3 && groups == 1 && identity_rep == 0 && Opad == O && Ipad == I) {
-    hipLaunchKernelGGL(fold_fwd_tile_kernel, dim3(ceil_div(I, 16), ceil_div(O, 16)), dim3(256), 0, s, W, D, D_diag, O, I, wp_f, wp_d);
+    P2I_LAUNCH(fold_fwd_tile_kernel, dim3(ceil_div(I, 16), ceil_div(O, 16)), dim3(256), 0, s, W, D, D_diag, O, I, wp_f, wp_d);
     return launch_status();
   }
   const int n = (ksz == 1) ? O * (I / groups) : (O / groups) * I;
-  hipLaunchKernelGGL(fold_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, W, D, D_diag, O, I, groups, ksz, identity_rep, wp_f, wp_d);
+  P2I_LAUNCH(fold_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, W, D, D_diag, O, I, groups, ksz, identity_rep, wp_f, wp_d);
   return launch_status();
 }
 
@@ -528,10 +528,10 @@ extern "C" int p2i_doconv_fold_bwd(const float* dwp_f, const float* W, const flo
   hipStream_t s = (hipStream_t)stream;
   const int n = (ksz == 1) ? O * (I / groups) : (O / groups) * I;
   if (ksz == 3 && groups == 1 && O % 32 == 0)
-    hipLaunchKernelGGL(fold_bwd_w_tile_kernel, dim3(ceil_div(I, 16), ceil_div(O, 16)), dim3(256), 0, s, dwp_f, D, D_diag, O, I, dW);
+    P2I_LAUNCH(fold_bwd_w_tile_kernel, dim3(ceil_div(I, 16), ceil_div(O, 16)), dim3(256), 0, s, dwp_f, D, D_diag, O, I, dW);
   else
-    hipLaunchKernelGGL(fold_bwd_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dwp_f, D, D_diag, O, I, groups, ksz, dW);
-  if (ksz == 3) hipLaunchKernelGGL(fold_bwd_d_kernel, dim3(I), dim3(256), 0, s, dwp_f, W, O, I, groups, dD);
+    P2I_LAUNCH(fold_bwd_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dwp_f, D, D_diag, O, I, groups, ksz, dW);
+  if (ksz == 3) P2I_LAUNCH(fold_bwd_d_kernel, dim3(I), dim3(256), 0, s, dwp_f, W, O, I, groups, dD);
   return launch_status();
 }
 
@@ -540,9 +540,9 @@ extern "C" int p2i_weight_pack(const float* w, int O, int I, int ntaps, const fl
   P2I_REQUIRE(w && (wp_f || wp_d), "null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int Opad = (O + 31) / 32 * 32, Ipad = (I + 31) / 32 * 32;
-  if (wp_f && Opad != O) (void)hipMemsetAsync(wp_f, 0, sizeof(float) * (size_t)ntaps * I * Opad, s);
-  if (wp_d && Ipad != I) (void)hipMemsetAsync(wp_d, 0, sizeof(float) * (size_t)ntaps * O * Ipad, s);
-  hipLaunchKernelGGL(pack_kernel, dim3(ceil_div(O * I * ntaps, 256)), dim3(256), 0, s, w, O, I, ntaps, inv_div_ptr, wp_f, wp_d);
+  if (wp_f && Opad != O) (void)p2i::memset_async(wp_f, 0, sizeof(float) * (size_t)ntaps * I * Opad, s);
+  if (wp_d && Ipad != I) (void)p2i::memset_async(wp_d, 0, sizeof(float) * (size_t)ntaps * O * Ipad, s);
+  P2I_LAUNCH(pack_kernel, dim3(ceil_div(O * I * ntaps, 256)), dim3(256), 0, s, w, O, I, ntaps, inv_div_ptr, wp_f, wp_d);
   return launch_status();
 }
 
@@ -553,10 +553,10 @@ extern "C" int p2i_weight_unpack_grad(const float* dwp_f, int O, int I, int ntap
   hipStream_t s = (hipStream_t)stream;
   const int n = O * I * ntaps;
   if (sigma_ptr) {
-    (void)hipMemsetAsync(scratch, 0, sizeof(float), s);
-    hipLaunchKernelGGL(unpack_dot_kernel, dim3(min(ceil_div(n, 256), 256)), dim3(256), 0, s, dwp_f, w_orig, O, I, ntaps, scratch);
+    (void)p2i::memset_async(scratch, 0, sizeof(float), s);
+    P2I_LAUNCH(unpack_dot_kernel, dim3(min(ceil_div(n, 256), 256)), dim3(256), 0, s, dwp_f, w_orig, O, I, ntaps, scratch);
   }
-  hipLaunchKernelGGL(unpack_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dwp_f, O, I, ntaps, sigma_ptr, scratch, u, v, dw);
+  P2I_LAUNCH(unpack_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dwp_f, O, I, ntaps, sigma_ptr, scratch, u, v, dw);
   return launch_status();
 }
 
@@ -567,14 +567,14 @@ extern "C" int p2i_spectral_norm(const float* w, int O, int K, float* u, float* 
   float* t = scratch;        // K
   float* sv = scratch + K;   // O
   if (training) {
-    (void)hipMemsetAsync(t, 0, sizeof(float) * K, s);
-    hipLaunchKernelGGL(sn_wtu_kernel, dim3(ceil_div(K, 64), ceil_div(O, 32)), dim3(256), 0, s, w, u, O, K, t);
-    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, t, K, v, (float*)nullptr);
-    hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(O, 4)), dim3(256), 0, s, w, v, O, K, sv);
-    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, sv, O, u, sigma);
+    (void)p2i::memset_async(t, 0, sizeof(float) * K, s);
+    P2I_LAUNCH(sn_wtu_kernel, dim3(ceil_div(K, 64), ceil_div(O, 32)), dim3(256), 0, s, w, u, O, K, t);
+    P2I_LAUNCH(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, t, K, v, (float*)nullptr);
+    P2I_LAUNCH(sn_wv_kernel, dim3(ceil_div(O, 4)), dim3(256), 0, s, w, v, O, K, sv);
+    P2I_LAUNCH(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, sv, O, u, sigma);
   } else {
-    hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(O, 4)), dim3(256), 0, s, w, v, O, K, sv);
-    hipLaunchKernelGGL(sn_dot_kernel, dim3(1), dim3(1024), 0, s, u, sv, O, sigma);
+    P2I_LAUNCH(sn_wv_kernel, dim3(ceil_div(O, 4)), dim3(256), 0, s, w, v, O, K, sv);
+    P2I_LAUNCH(sn_dot_kernel, dim3(1), dim3(1024), 0, s, u, sv, O, sigma);
   }
   return launch_status();
 }
@@ -596,13 +596,13 @@ extern "C" int p2i_spectral_norm_batched(const float* const* w, const int* O, co
   b.n = n;
   hipStream_t s = (hipStream_t)stream;
   if (training) {
-    hipLaunchKernelGGL(sn_wtu_batched_kernel, dim3(ceil_div(maxK, 64), 1, n), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(sn_finish_batched_kernel, dim3(1, 1, n), dim3(1024), 0, s, b, 0);
-    hipLaunchKernelGGL(sn_wv_batched_kernel, dim3(ceil_div(maxO, 4), 1, n), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(sn_finish_batched_kernel, dim3(1, 1, n), dim3(1024), 0, s, b, 1);
+    P2I_LAUNCH(sn_wtu_batched_kernel, dim3(ceil_div(maxK, 64), 1, n), dim3(256), 0, s, b);
+    P2I_LAUNCH(sn_finish_batched_kernel, dim3(1, 1, n), dim3(1024), 0, s, b, 0);
+    P2I_LAUNCH(sn_wv_batched_kernel, dim3(ceil_div(maxO, 4), 1, n), dim3(256), 0, s, b);
+    P2I_LAUNCH(sn_finish_batched_kernel, dim3(1, 1, n), dim3(1024), 0, s, b, 1);
   } else {
-    hipLaunchKernelGGL(sn_wv_batched_kernel, dim3(ceil_div(maxO, 4), 1, n), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(sn_finish_batched_kernel, dim3(1, 1, n), dim3(1024), 0, s, b, 2);
+    P2I_LAUNCH(sn_wv_batched_kernel, dim3(ceil_div(maxO, 4), 1, n), dim3(256), 0, s, b);
+    P2I_LAUNCH(sn_finish_batched_kernel, dim3(1, 1, n), dim3(1024), 0, s, b, 2);
   }
   return launch_status();
 }
@@ -617,7 +617,7 @@ extern "C" int p2i_doconv_fold_fwd_batched(const float* const* W, const float* c
     P2I_REQUIRE(W[i] && D[i] && D_diag[i] && wp_f[i], "null pointer (layer %d)", i);
     fb.W[i] = W[i]; fb.D[i] = D[i]; fb.Dd[i] = D_diag[i]; fb.a[i] = wp_f[i]; fb.b[i] = wp_d ? wp_d[i] : nullptr;
   }
-  hipLaunchKernelGGL(fold_fwd_tile_batched_kernel, dim3(I / 32, O / 32, n), dim3(256), 0, (hipStream_t)stream, fb, O, I);
+  P2I_LAUNCH(fold_fwd_tile_batched_kernel, dim3(I / 32, O / 32, n), dim3(256), 0, (hipStream_t)stream, fb, O, I);
   return launch_status();
 }
 extern "C" int p2i_doconv_fold_bwd_batched(const float* const* dwp_f, const float* const* W, const float* const* D,
@@ -631,8 +631,8 @@ extern "C" int p2i_doconv_fold_bwd_batched(const float* const* dwp_f, const floa
     fb.g[i] = dwp_f[i]; fb.W[i] = W[i]; fb.D[i] = D[i]; fb.Dd[i] = D_diag[i]; fb.a[i] = dW[i]; fb.b[i] = dD[i];
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(fold_bwd_w_tile_batched_kernel, dim3(I / 32, O / 32, n), dim3(256), 0, s, fb, O, I);
-  hipLaunchKernelGGL(fold_bwd_d_batched_kernel, dim3(I / 32, 1, n), dim3(256), 0, s, fb, O, I);
+  P2I_LAUNCH(fold_bwd_w_tile_batched_kernel, dim3(I / 32, O / 32, n), dim3(256), 0, s, fb, O, I);
+  P2I_LAUNCH(fold_bwd_d_batched_kernel, dim3(I / 32, 1, n), dim3(256), 0, s, fb, O, I);
   return launch_status();
 }
 
@@ -701,7 +701,7 @@ extern "C" int p2i_weight_pack_batched(const float* const* w, const int* O, cons
     if (O[i] * I[i] * ntaps[i] > maxn) maxn = O[i] * I[i] * ntaps[i];
   }
   const int blocks = ceil_div(maxn, 256);
-  hipLaunchKernelGGL(pack_batched_kernel, dim3(blocks > 512 ? 512 : blocks, 1, n), dim3(256), 0, (hipStream_t)stream, b);
+  P2I_LAUNCH(pack_batched_kernel, dim3(blocks > 512 ? 512 : blocks, 1, n), dim3(256), 0, (hipStream_t)stream, b);
   return launch_status();
 }
 
@@ -727,10 +727,10 @@ extern "C" int p2i_weight_unpack_grad_batched_acc(const float* const* dwp_f, con
   hipStream_t s = (hipStream_t)stream;
   const int blocks = ceil_div(maxn, 256);
   if (any_sigma) {
-    (void)hipMemsetAsync(dots, 0, sizeof(float) * n, s);
-    hipLaunchKernelGGL(unpack_dot_batched_kernel, dim3(blocks > 128 ? 128 : blocks, 1, n), dim3(256), 0, s, b);
+    (void)p2i::memset_async(dots, 0, sizeof(float) * n, s);
+    P2I_LAUNCH(unpack_dot_batched_kernel, dim3(blocks > 128 ? 128 : blocks, 1, n), dim3(256), 0, s, b);
   }
-  hipLaunchKernelGGL(unpack_batched_kernel, dim3(blocks > 512 ? 512 : blocks, 1, n), dim3(256), 0, s, b);
+  P2I_LAUNCH(unpack_batched_kernel, dim3(blocks > 512 ? 512 : blocks, 1, n), dim3(256), 0, s, b);
   return launch_status();
 }
 

@@ -665,7 +665,7 @@ static int launch_wgrad_reduce(const float* ws, int ns, long long slice, int Co,
   while (lsg < 3 && (2 << lsg) <= ns && (n4 >> (8 - lsg)) < 512) ++lsg;
   const int ncol = 256 >> lsg;
   const int blocks = (n4 + ncol - 1) / ncol;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, s, ws, ns, slice, n4, Co, CoPad, lsg, dwp);
+  P2I_LAUNCH(wgrad_reduce_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, s, ws, ns, slice, n4, Co, CoPad, lsg, dwp);
   return launch_status();
 }
 
@@ -828,7 +828,7 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
         const bool sliced = ns >= 2 && g_wgrad_ws != nullptr && slice * ns <= g_wgrad_ws_floats && slice < (1ll << 31);
         ga.partial = sliced ? g_wgrad_ws : nullptr;
         ga.pstride = slice;
-        hipLaunchKernelGGL(kern, dim3(ns, ncb, nco), dim3(512), lds2, s, ga);
+        P2I_LAUNCH(kern, dim3(ns, ncb, nco), dim3(512), lds2, s, ga);
         if (int e = launch_status()) return e;
         if (sliced)
           if (int e = launch_wgrad_reduce(g_wgrad_ws, ns, slice, d->Cout, g.CoPad, ga.dwp, s)) return e;
@@ -843,7 +843,7 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
     ga.tpg = g.tpg;
     ga.dwp = dwp + (size_t)a * g.tpg * d->Cin * g.CoPad;
     for (int i = 0; i < g.tpg; ++i) ga.tap_off[i] = g.tap_off[a * g.tpg + i];
-    hipLaunchKernelGGL(wgrad_kernel<NPIX>, dim3(nsplit, ncx, nco), dim3(256), lds, s, ga);
+    P2I_LAUNCH(wgrad_kernel<NPIX>, dim3(nsplit, ncx, nco), dim3(256), lds, s, ga);
     if (int e = launch_status()) return e;
   }
   if (dbias && !bias_fused) return p2i_bias_grad(dy, y_act, act, dbias, d->B, d->Cout, (int64_t)d->To * d->Ho * d->Wo, stream);

@@ -585,7 +585,7 @@ int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float*
   // (the convolution consumers 0.6-0.75 16-byte reads) and has no partner wave on its SIMD to cover the 2-way conflicted ones.  Kept as
   // an option (same results, tested); read per call.
   const char* pce = getenv("P2I_WGRAD_X6_PC");
-  if (pce != nullptr && atoi(pce) != 0) hipLaunchKernelGGL(wgrad_x6p_kernel, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
+  if (pce != nullptr && atoi(pce) != 0) P2I_LAUNCH(wgrad_x6p_kernel, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
   // conflict-free row assignment of the transposed reads (wx_read_tr_s4): the default; P2I_WGRAD_X6_S4=0 keeps round 2's rows (A/B, read
   // per call).  Measured in one box (gpurun_out/r03x/wg_s0.log, wg_s4.log, wg_s0b.log; PMC: gpurun_out/r03x/pmc): conflict cycles 43 % ->
   // 0.5 % of the LDS cycles, launch time within 1 % (66.5-71.5 us either way): the transposed reads were never what the kernel waits for.
@@ -594,15 +594,15 @@ int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float*
     const int dg = atoi(getenv("P2I_WGRAD_DIAG"));
     const dim3 gr(ns, ncb, nco * d->kt);
 #define WX_DIAG_CASE(n) case n: { static bool a_ = false; if (!a_) { (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel<true, n>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a_ = true; } \
-      hipLaunchKernelGGL((wgrad_x6_kernel<true, n>), gr, dim3(512), 2 * WX_BUF + 1024, s, g); break; }
+      P2I_LAUNCH((wgrad_x6_kernel<true, n>), gr, dim3(512), 2 * WX_BUF + 1024, s, g); break; }
     switch (dg) { WX_DIAG_CASE(1) WX_DIAG_CASE(2) WX_DIAG_CASE(3) WX_DIAG_CASE(4) WX_DIAG_CASE(8) WX_DIAG_CASE(12) WX_DIAG_CASE(11) WX_DIAG_CASE(7)
-      default: hipLaunchKernelGGL(wgrad_x6_kernel<true>, gr, dim3(512), 2 * WX_BUF + 1024, s, g); }
+      default: P2I_LAUNCH(wgrad_x6_kernel<true>, gr, dim3(512), 2 * WX_BUF + 1024, s, g); }
 #undef WX_DIAG_CASE
   }
 #endif
   else if (!(getenv("P2I_WGRAD_X6_S4") && atoi(getenv("P2I_WGRAD_X6_S4")) == 0))
-    hipLaunchKernelGGL(wgrad_x6_kernel<true>, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
-  else hipLaunchKernelGGL(wgrad_x6_kernel<false>, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
+    P2I_LAUNCH(wgrad_x6_kernel<true>, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
+  else P2I_LAUNCH(wgrad_x6_kernel<false>, dim3(ns, ncb, nco * d->kt), dim3(512), 2 * WX_BUF + 1024, s, g);
   *ns_out = sliced ? ns : 0;
   *slice_out = slice;
   return launch_status();

@@ -79,6 +79,13 @@ SIGNATURES = {
     "p2i_act_bwd": [_P, _P, _I, _P, _L, _P],
     "p2i_bias_grad": [_P, _P, _I, _P, _I, _I, _L, _P],
     "p2i_act_bwd_bias": [_P, _P, _I, _P, _P, _I, _I, _L, _P],
+    "p2i_event_record": [_I, _P],
+    "p2i_event_wait": [_I, _P],
+    "p2i_tape_begin": [_P],
+    "p2i_tape_end": [C.POINTER(C.c_void_p)],
+    "p2i_tape_info": [_P, C.POINTER(C.c_int)],
+    "p2i_tape_replay": [_P, _P],
+    "p2i_tape_free": [_P],
 }
 
 

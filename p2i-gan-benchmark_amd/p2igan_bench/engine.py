@@ -114,14 +114,21 @@ class TrainEngine:
         return self._level_ranges[lvl]
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
-    def capture(self, frames, masked, masks, warmup: int = 3):
-        """Capture ONE full G+D iteration (forward, both backward passes, both Adam steps: ~800 launches) into a
-        hipGraph and replay it from then on: the step has no host sync and static shapes, so the ~3-5 us dispatch gap
-        between dependent launches shrinks to the graph's ~1 us.  `warmup` eager steps run first (they are real
-        training steps) so that every lazily built table and kernel attribute exists before the capture.  Single
-        process only: the data-parallel path keeps eager launches around its RCCL exchange."""
+    def capture(self, frames, masked, masks, warmup: int = 3, mode: str = "graph"):
+        """Capture ONE full G+D iteration (forward, both backward passes, both Adam steps: ~800 launches) and replay it from
+        then on.  `warmup` eager steps run first (they are real training steps) so that every lazily built table and kernel
+        attribute exists before the capture.  Single process only: the data-parallel path keeps eager launches around its RCCL
+        exchange.
+        mode "graph": replay the captured hipGraph (hipGraphLaunch of the ~800-node graph costs the host as much as the launches
+        themselves on ROCm 7.2).
+        mode "tape" (round 4, the native step sequencer of include/p2i_hip.h): while the step is being captured the library also
+        RECORDS its launches, memsets and stream dependencies on a launch tape; train_step then re-enqueues the tape with one C
+        call (p2i_tape_replay) -- ~2 us per launch instead of ~9 us of Python / ctypes work.  The capture is kept for its private
+        memory pool only (every buffer the tape names lives there, at a fixed address); the hipGraph itself is never launched."""
         if self.distributed:
             raise RuntimeError("graph capture is for the single-GPU step")
+        if mode not in ("graph", "tape"):
+            raise ValueError(mode)
         for o in (self.opt_g, self.opt_d):
             if o is not None:
                 o.use_device_step()
@@ -135,8 +142,19 @@ class TrainEngine:
                 self._step_impl(*self._static_in)
         torch.cuda.current_stream().wait_stream(side)
         self._graph = torch.cuda.CUDAGraph()
+        self._tape = None
+        import ctypes
+        lib = ops._hip.load()
         with torch.cuda.graph(self._graph):
-            self._static_out = self._step_impl(*self._static_in)
+            if mode == "tape":
+                ops._hip.check(lib.p2i_tape_begin(torch.cuda.current_stream().cuda_stream), "p2i_tape_begin")
+            try:
+                self._static_out = self._step_impl(*self._static_in)
+            finally:
+                if mode == "tape":
+                    handle = ctypes.c_void_p()
+                    ops._hip.check(lib.p2i_tape_end(ctypes.byref(handle)), "p2i_tape_end")
+                    self._tape = handle
         self._host_steps_per_replay = 1
         # the capture itself executed nothing: undo the host-side counters it bumped
         for o in (self.opt_g, self.opt_d):
@@ -144,7 +162,16 @@ class TrainEngine:
                 o.step_count -= 1
         return warmup
 
-    # Automatic graph replay (opt-in: P2I_AUTO_GRAPH=1).  Measured in round 3 (gpurun_out/r03a/loader_probe.log, profiles/README.md):
+    def tape_info(self):
+        """(kernels, memsets, event operations, streams) of the recorded step, or None."""
+        if getattr(self, "_tape", None) is None:
+            return None
+        import ctypes
+        c = (ctypes.c_int * 4)()
+        ops._hip.check(ops._hip.load().p2i_tape_info(self._tape, c), "p2i_tape_info")
+        return tuple(c)
+
+    # Automatic graph replay (opt-in: P2I_AUTO_GRAPH=1; P2I_AUTO_TAPE=1: the same trigger, replay through the launch tape).  Measured in round 3 (gpurun_out/r03a/loader_probe.log, profiles/README.md):
     # hipGraphLaunch of the ~800-node step costs the host 6-10 ms, i.e. as much as enqueueing the launches one by one (B=1: 8.97 ms
     # replayed vs 8.21 ms eager; B=8: 15.8 vs 15.6), so replay does not lift the launch bound of small steps on ROCm 7.2 and is
     # not the default.  With P2I_AUTO_GRAPH=1 the engine captures by itself once the same input shapes have repeated
@@ -153,7 +180,7 @@ class TrainEngine:
 
     def _auto_graph_wanted(self, frames) -> bool:
         import os
-        if os.environ.get("P2I_AUTO_GRAPH", "0") != "1":
+        if os.environ.get("P2I_AUTO_GRAPH", "0") != "1" and os.environ.get("P2I_AUTO_TAPE", "0") != "1":
             return False
         return not (self.distributed or not self.direct or self.phase_marks is not None or ops.PROFILE is not None)
 
@@ -164,7 +191,10 @@ class TrainEngine:
                 for dst, src in zip(self._static_in, (frames, masked, masks)):
                     if dst.data_ptr() != src.data_ptr():
                         dst.copy_(src)
-                self._graph.replay()
+                if getattr(self, "_tape", None) is not None:
+                    ops._hip.check(ops._hip.load().p2i_tape_replay(self._tape, torch.cuda.current_stream().cuda_stream), "p2i_tape_replay")
+                else:
+                    self._graph.replay()
                 for o in (self.opt_g, self.opt_d):
                     if o is not None:
                         o.step_count += 1
@@ -176,7 +206,8 @@ class TrainEngine:
             self._same_shape_steps = getattr(self, "_same_shape_steps", 0) + 1 if getattr(self, "_last_shape", None) == shp else 0
             self._last_shape = shp
             if self._same_shape_steps >= self.AUTO_GRAPH_AFTER:
-                self.capture(frames, masked, masks, warmup=0)
+                import os
+                self.capture(frames, masked, masks, warmup=0, mode="tape" if os.environ.get("P2I_AUTO_TAPE", "0") == "1" else "graph")
                 return self.train_step(frames, masked, masks)
         return self._step_impl(frames, masked, masks)
 
@@ -221,8 +252,7 @@ class TrainEngine:
             if side is not None:
                 b_, t_, c_, h_, w_ = masked.shape
                 gprep = side.run(lambda: net_fns.generator_prepare(G, b_, h_, w_))
-                ev_g = side.mark()
-                ready = lambda: torch.cuda.current_stream().wait_event(ev_g)
+                ready = side.mark()                   # the main stream waits for the prepared weights, not for the rest of the side work
                 if self.use_gan:
                     if not D.training:
                         D.train()

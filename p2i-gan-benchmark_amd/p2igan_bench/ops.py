@@ -257,9 +257,8 @@ class SideStream:
         self.pending = False
 
     def run(self, fn, *tensors):
-        ev = torch.cuda.Event()
-        ev.record()                                    # everything enqueued on the main stream so far (producers of `tensors`)
-        self.stream.wait_event(ev)
+        # everything enqueued on the forking stream so far (producers of `tensors`) -> this side stream
+        fork(_stream(), self.stream.cuda_stream)
         global _CUR_STREAM, _SIDE_DEPTH
         prev, _CUR_STREAM = _CUR_STREAM, self.stream.cuda_stream
         _SIDE_DEPTH += 1
@@ -274,18 +273,37 @@ class SideStream:
         return out
 
     def mark(self):
-        """An event after everything enqueued on the side stream so far (the main stream can wait for PART of the side work)."""
-        ev = torch.cuda.Event()
-        ev.record(self.stream)
-        return ev
+        """A wait token after everything enqueued on the side stream so far (the main stream can wait for PART of the side work):
+        call it -- token() -- on the thread of control whose current stream shall wait."""
+        slot = _next_slot()
+        _hip.check(_hip.load().p2i_event_record(slot, self.stream.cuda_stream), "p2i_event_record")
+        return lambda: _hip.check(_hip.load().p2i_event_wait(slot, _stream()), "p2i_event_wait")
 
     def join(self):
         if self.pending:
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-            torch.cuda.current_stream().wait_event(ev)
+            fork(self.stream.cuda_stream, _stream())
             self.pending = False
         self.keep.clear()
+
+
+# Cross-stream dependencies go through the library's event table (p2i_event_record / p2i_event_wait: 256 slots of events without
+# timing, include/p2i_hip.h) instead of torch.cuda.Event objects: a launch tape (p2i_tape_*) sees them, and a fork costs two ctypes
+# calls instead of an event allocation + record + wait through torch.  Slots are handed out round-robin; a step uses ~40.
+_SLOT = 0
+
+
+def _next_slot() -> int:
+    global _SLOT
+    _SLOT = (_SLOT + 1) % 256
+    return _SLOT
+
+
+def fork(src_stream: int, dst_stream: int):
+    """dst_stream waits for everything enqueued on src_stream so far (raw HIP stream handles)."""
+    lib = _hip.load()
+    slot = _next_slot()
+    _hip.check(lib.p2i_event_record(slot, src_stream), "p2i_event_record")
+    _hip.check(lib.p2i_event_wait(slot, dst_stream), "p2i_event_wait")
 
 
 def pad32(n: int) -> int:

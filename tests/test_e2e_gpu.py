@@ -451,9 +451,11 @@ def test_inference_variant_and_weight_cache(dev, golden):
         Ge(masked, masks)
 
 
-def test_graph_replay_matches_eager_steps(dev):
-    """TrainEngine.capture(): the hipGraph replay of the whole G+D step (device-side Adam step counter) follows the
-    eager engine.  Compared at step 2 (one eager warm-up step + one replay): the float atomics of a few small reductions
+@pytest.mark.parametrize("mode", ["graph", "tape"])
+def test_graph_replay_matches_eager_steps(dev, mode):
+    """TrainEngine.capture(): the replay of the whole G+D step (device-side Adam step counter) -- as a hipGraph, or through the
+    library's launch tape (p2i_tape_replay, the native step sequencer: every launch, memset and stream dependency of the recorded
+    step re-enqueued by one C call) -- follows the eager engine.  Compared at step 2 (one eager warm-up step + one replay): the float atomics of a few small reductions
     make two EAGER runs drift apart too (beta1 = 0 Adam amplifies sign flips: ~1e-7 at step 2, ~4e-3 in loss_g by step
     5, measured), so a later comparison would test that chaos, not the replay."""
     from p2igan_bench.engine import TrainEngine
@@ -463,8 +465,11 @@ def test_graph_replay_matches_eager_steps(dev):
         cfg, G, D = _build(dev)
         eng = TrainEngine(G, D, cfg)
         if graph:
-            assert eng.capture(frames, masked, masks, warmup=1) == 1
+            assert eng.capture(frames, masked, masks, warmup=1, mode=mode) == 1
             assert eng.opt_g.step_count == 1 and int(eng.opt_g.step_dev) == 1
+            if mode == "tape":
+                nk, nm, ne, nstreams = eng.tape_info()
+                assert nk > 300 and nm > 5 and ne >= 20 and nstreams == 3, (nk, nm, ne, nstreams)     # main + the two side streams
         else:
             eng.train_step(frames, masked, masks)
         r = eng.train_step(frames, masked, masks)
@@ -472,6 +477,11 @@ def test_graph_replay_matches_eager_steps(dev):
         if graph:
             assert int(eng.opt_g.step_dev) == 2 and int(eng.opt_d.step_dev) == 2
         res.append(({k: float(r[k]) for k in ("loss_g", "loss_d", "rec")}, r["preds"].clone(), eng.gp.flat.clone(), eng.dp.flat.clone()))
+        if graph and mode == "tape":                  # a third and fourth step through the tape: the counters and the weights keep moving
+            before = eng.gp.flat.clone()
+            eng.train_step(frames, masked, masks)
+            r4 = eng.train_step(frames, masked, masks)
+            assert int(eng.opt_g.step_dev) == 4 and float((eng.gp.flat - before).abs().max()) > 0 and bool(torch.isfinite(r4["loss_g"]))
     (la, pa, ga, da), (lb, pb, gb, db) = res
     for k in la:
         assert abs(la[k] - lb[k]) <= 1e-4 * abs(la[k]), (k, la[k], lb[k])

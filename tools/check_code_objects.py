@@ -29,6 +29,9 @@ def kernels_of(obj: str):
     import yaml
     with tempfile.TemporaryDirectory() as td:
         fat, co = os.path.join(td, "fat"), os.path.join(td, "co")
+        sections = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "-S", obj], text=True)
+        if ".hip_fatbin" not in sections:            # host-only translation unit (tape.hip): no kernels
+            return []
         subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", obj])
         subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", f"--targets={TARGET}", f"--input={fat}",
                                f"--output={co}", "--unbundle"])
