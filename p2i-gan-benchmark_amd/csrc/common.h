@@ -93,4 +93,34 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return s;
 }
 
+// ---- deterministic cross-workgroup sums ("last block done", no second launch, no spinning).  The small reductions of the step
+// (bias / position / attention-weight / alpha gradients, a few dot products) used to end in float atomics, whose order -- hence
+// whose rounding -- changes from run to run.  With a caller-owned scratch they are summed in a FIXED order instead: every workgroup of
+// a group stores its partial, makes it visible (__threadfence) and takes a ticket from the group's counter; the workgroup that draws
+// the last ticket adds the group's partials in workgroup order and resets the counter to 0 for the next call on the stream (the
+// counters must be zero before the first use; kernels of one stream never overlap, so one counter array per stream serves every
+// call).  Returns true, in every thread of that last workgroup, once all partials of the group are visible.
+struct DetWs {
+  float* part;          // partial sums (layout: per kernel)
+  unsigned* counter;    // >= number of groups, zero-initialised, self-resetting
+};
+__device__ __forceinline__ bool det_last_block(unsigned* counter, unsigned nblocks) {
+  __shared__ int det_last_;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = atomicAdd(counter, 1u);
+    det_last_ = prev == nblocks - 1 ? 1 : 0;
+    if (det_last_) *counter = 0;
+  }
+  __syncthreads();
+  if (det_last_) __threadfence();
+  return det_last_ != 0;
+}
+// a partial written by another workgroup: bypass this CU's L1 (which is not coherent with the other CUs' stores)
+__device__ __forceinline__ float det_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// host: this call's share of the scratch registered with p2i_det_workspace ({nullptr, nullptr}: none registered, or too small --
+// the kernels then keep their float atomics)
+DetWs det_take(size_t floats, int counters);
+
 }  // namespace p2i

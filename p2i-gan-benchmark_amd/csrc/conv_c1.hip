@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void c1_dgrad_fast_kernel(const p2i_conv_desc 
 // positions.  Persistent workgroups over (b, to, 4 rows x 64 columns) tiles; wave = one tile row; per-wave partial tiles are
 // summed through LDS and added to dwp / dbias with one float atomic per element per workgroup (256-B segments: full rate).
 __global__ __launch_bounds__(256) void c1_wgrad_mfma_kernel(const p2i_conv_desc d, const float* __restrict__ x, const float* __restrict__ dy,
-                                                           float* dwp, float* dbias, int nth, int ntw, int ntiles) {
+                                                           float* dwp, float* dbias, int nth, int ntw, int ntiles, DetWs ws) {
   constexpr int PP = C1_ROWS * C1_TW + 4;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* sx = sm;                                        // [3][EH][EW] + {1, 0}
@@ -446,6 +446,40 @@ __global__ __launch_bounds__(256) void c1_wgrad_mfma_kernel(const p2i_conv_desc 
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
   __syncthreads();
+  if (ws.counter) {
+    // deterministic: two levels of last-workgroup-done.  ws.part = [gridDim.x][28 x 32] workgroup partials, then [groups][28 x 32]
+    // group sums; groups of C1_DG consecutive workgroups; counters: one per group, then one for the groups.
+    constexpr int C1_DG = 16, PT = 28 * 32;
+    const unsigned nblk = gridDim.x, ngrp = (nblk + C1_DG - 1) / C1_DG, grp = blockIdx.x / C1_DG;
+    const unsigned gsz = min((unsigned)C1_DG, nblk - grp * C1_DG);
+    float* p1 = ws.part;
+    float* p2 = ws.part + (size_t)nblk * PT;
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = (red[r * 64 + lane] + red[(16 + r) * 64 + lane]) + (red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane]);
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row < 28) p1[(size_t)blockIdx.x * PT + row * 32 + l31] = v;
+      }
+    }
+    if (!det_last_block(ws.counter + grp, gsz)) return;
+    for (int e = threadIdx.x; e < PT; e += 256) {
+      float sacc = 0.f;
+      for (unsigned k = 0; k < gsz; ++k) sacc += det_load(p1 + (size_t)(grp * C1_DG + k) * PT + e);
+      p2[(size_t)grp * PT + e] = sacc;
+    }
+    if (!det_last_block(ws.counter + ngrp, ngrp)) return;
+    for (int e = threadIdx.x; e < PT; e += 256) {
+      float sacc = 0.f;
+      for (unsigned k = 0; k < ngrp; ++k) sacc += det_load(p2 + (size_t)k * PT + e);
+      const int row = e >> 5, oc = e & 31;
+      if (oc < d.Cout) {
+        if (row < 27) dwp[row * 32 + oc] += sacc;
+        else if (dbias) dbias[oc] += sacc;
+      }
+    }
+    return;
+  }
   if (wave == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -491,7 +525,9 @@ static int c1_wgrad_mfma(const p2i_conv_desc* d, const float* x, const float* dy
     attr_set = true;
   }
   const int grid = ntiles < 512 ? (int)ntiles : 512;
-  P2I_LAUNCH(c1_wgrad_mfma_kernel, dim3(grid), dim3(256), lds, s, *d, x, dy, dwp, dbias, nth, ntw, (int)ntiles);
+  const int ngrp = (grid + 15) / 16;
+  const DetWs ws = det_take((size_t)(grid + ngrp) * 28 * 32, ngrp + 1);
+  P2I_LAUNCH(c1_wgrad_mfma_kernel, dim3(grid), dim3(256), lds, s, *d, x, dy, dwp, dbias, nth, ntw, (int)ntiles, ws);
   return launch_status();
 }
 

@@ -54,7 +54,7 @@ template <int T>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                        const float* __restrict__ b0, const float* __restrict__ w1,
                                                        const float* __restrict__ b1, const float* __restrict__ dout,
-                                                       float* dw0, float* db0, float* dw1, float* db1, int B, int HW) {
+                                                       float* dw0, float* db0, float* dw1, float* db1, int B, int HW, DetWs ws) {
   constexpr int NP = T * T + T;                        // parameters per layer: weight rows then bias
   constexpr int NE = (2 * NP + 255) / 256;             // parameter elements per thread
   constexpr int PPT = (ATTN_LIST * T + 255) / 256;     // (listed pixel, element) pairs per thread: 4 / 2 / 1 at T = 32 / 16 / 8
@@ -85,7 +85,38 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   int rank = __popcll(bal & ((1ull << lane) - 1ull)), nact = 0;
 #pragma unroll
   for (int w = 0; w < 4; ++w) { if (w < wave) rank += wave_cnt[w]; nact += wave_cnt[w]; }
-  if (nact == 0) return;                               // block-uniform
+  // deterministic mode (ws.counter): every workgroup takes a ticket; ws.part = [nblk] "has a partial" flags, then [nblk][2 NP] partials
+  const unsigned nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+  auto det_finish = [&]() {
+    if (!det_last_block(ws.counter, nblk)) return;
+    int* vlist = act;                                  // the workgroups that hold a partial, in workgroup order (LDS: act[] is free now)
+    __shared__ int nvalid;
+    if (threadIdx.x == 0) {
+      int n = 0;
+      for (unsigned b2 = 0; b2 < nblk; ++b2)
+        if (det_load(ws.part + b2) != 0.f) { if (n < 256) vlist[n] = (int)b2; ++n; }
+      nvalid = n;
+    }
+    __syncthreads();
+    const float* pp = ws.part + nblk;
+    for (int e = threadIdx.x; e < 2 * NP; e += 256) {
+      float sacc = 0.f;
+      if (nvalid <= 256) { for (int i = 0; i < nvalid; ++i) sacc += det_load(pp + (size_t)vlist[i] * 2 * NP + e); }
+      else { for (unsigned b2 = 0; b2 < nblk; ++b2) if (det_load(ws.part + b2) != 0.f) sacc += det_load(pp + (size_t)b2 * 2 * NP + e); }
+      const int l = e >= NP ? 1 : 0, q = e - l * NP;
+      float* dw = l ? dw1 : dw0;
+      float* db = l ? db1 : db0;
+      float* o = q < T * T ? dw + q : db + (q - T * T);
+      *o += sacc;
+    }
+  };
+  if (nact == 0) {                                     // block-uniform
+    if (ws.counter) {
+      if (threadIdx.x == 0) ws.part[blk] = 0.f;
+      det_finish();
+    }
+    return;
+  }
   if (any) act[rank] = p;
 
   // element e of this thread: layer l = e / NP, index q = e % NP; q < T*T: weight (i, j) = (q / T, q % T) <- dg[i] * h[j]; else bias
@@ -160,6 +191,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       }
       acc[k] = a;
     }
+  }
+  if (ws.counter) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      if (e < 2 * NP) ws.part[nblk + (size_t)blk * 2 * NP + e] = acc[k];
+    }
+    if (threadIdx.x == 0) ws.part[blk] = 1.f;
+    __syncthreads();                                   // (act[] is reused by det_finish)
+    det_finish();
+    return;
   }
 #pragma unroll
   for (int k = 0; k < NE; ++k) {
@@ -246,11 +288,13 @@ __global__ __launch_bounds__(256) void upmod_fwd_kernel(const float* __restrict_
 }
 // dpos[y,x] += sum_{bc in chunk} du * v * 2 s (1-s);   grid.y = bc chunks
 __global__ void upmod_bwd_pos_kernel(const float* __restrict__ x, const float* __restrict__ pos, const float* __restrict__ du,
-                                     float* dpos, int BC, int Sh, int Sw, int chunk) {
+                                     float* dpos, int BC, int Sh, int Sw, int chunk, DetWs ws) {
   const int Oh = 2 * Sh, Ow = 2 * Sw;
   const float sch = (float)(Sh - 1) / (float)(Oh - 1), scw = (float)(Sw - 1) / (float)(Ow - 1);
-  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= Oh * Ow) return;
+  const int pix0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool pvalid = pix0 < Oh * Ow;
+  const int pix = pvalid ? pix0 : Oh * Ow - 1;         // (deterministic mode: every thread stays for the workgroup's ticket)
+  if (!pvalid && !ws.counter) return;
   const int ox = pix % Ow, oy = pix / Ow;
   int y0, y1, x0, x1; float ly, lx;
   ac_src(oy, sch, Sh, y0, y1, ly);
@@ -264,7 +308,19 @@ __global__ void upmod_bwd_pos_kernel(const float* __restrict__ x, const float* _
     acc += du[(size_t)bc * Oh * Ow + pix] * v;
   }
   const float sg = 1.f / (1.f + expf(-pos[pix]));
-  atomicAdd(dpos + pix, acc * 2.f * sg * (1.f - sg));
+  const float contrib = acc * 2.f * sg * (1.f - sg);
+  if (ws.counter) {
+    // group = the gridDim.y channel-chunk workgroups of this pixel block; ws.part = [gridDim.y][gridDim.x * 256]
+    const size_t npad = (size_t)gridDim.x * blockDim.x;
+    ws.part[(size_t)blockIdx.y * npad + pix0] = contrib;
+    if (det_last_block(ws.counter + blockIdx.x, gridDim.y) && pvalid) {
+      float sacc = 0.f;
+      for (unsigned y = 0; y < gridDim.y; ++y) sacc += det_load(ws.part + (size_t)y * npad + pix0);
+      dpos[pix] += sacc;
+    }
+    return;
+  }
+  atomicAdd(dpos + pix, contrib);
 }
 // dx[bc, yi, xi] = sum over the output pixels that sample (yi, xi) of weight * du * (1 + posm).  Thread = one INPUT pixel for a
 // chunk of channels: the <= 6 x 6 (weight * modulation) factors are computed once per thread (they held an expf and two
@@ -341,7 +397,7 @@ __global__ void dtail_fwd_kernel(const float* __restrict__ o2, const float* __re
   fused[idx] = sg * o2[idx] + up;
 }
 __global__ void dtail_bwd2_kernel(const float* __restrict__ o2, const float* __restrict__ alpha, const float* __restrict__ df,
-                                  float* do2, float* dalpha, int n) {
+                                  float* do2, float* dalpha, int n, DetWs ws) {
   __shared__ float red[16];
   const float sg = 1.f / (1.f + expf(-*alpha));
   float acc = 0.f;
@@ -351,6 +407,15 @@ __global__ void dtail_bwd2_kernel(const float* __restrict__ o2, const float* __r
     acc += g * o2[i];
   }
   acc = block_sum(acc, red);
+  if (dalpha && ws.counter) {
+    if (threadIdx.x == 0) ws.part[blockIdx.x] = acc * sg * (1.f - sg);
+    if (det_last_block(ws.counter, gridDim.x) && threadIdx.x == 0) {
+      float sacc = 0.f;
+      for (unsigned b2 = 0; b2 < gridDim.x; ++b2) sacc += det_load(ws.part + b2);
+      *dalpha += sacc;
+    }
+    return;
+  }
   if (dalpha && threadIdx.x == 0) atomicAdd(dalpha, acc * sg * (1.f - sg));
 }
 __global__ void dtail_bwd3_kernel(const float* __restrict__ df, float* do3, int B, int H2, int W2, int T3, int H3, int W3) {
@@ -382,7 +447,7 @@ __global__ void dtail_bwd3_kernel(const float* __restrict__ df, float* do3, int 
 // ------------------------------------------------------------------ misc
 // db[c] += sum_{b, inner} dy * act'(y); grid (C, chunks): block partial sums combined by one atomic each
 __global__ void bias_grad_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, float* db, int B, int C,
-                                 int64_t inner) {
+                                 int64_t inner, DetWs ws) {
   __shared__ float red[16];
   const int c = blockIdx.x;
   const int64_t total = (int64_t)B * inner;
@@ -397,12 +462,21 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, const float* __re
     acc += g;
   }
   acc = block_sum(acc, red);
+  if (ws.counter) {                                    // group = the gridDim.y chunk workgroups of channel c; ws.part = [C][gridDim.y]
+    if (threadIdx.x == 0) ws.part[(size_t)c * gridDim.y + blockIdx.y] = acc;
+    if (det_last_block(ws.counter + c, gridDim.y) && threadIdx.x == 0) {
+      float sacc = 0.f;
+      for (unsigned k = 0; k < gridDim.y; ++k) sacc += det_load(ws.part + (size_t)c * gridDim.y + k);
+      db[c] += sacc;
+    }
+    return;
+  }
   if (threadIdx.x == 0) atomicAdd(db + c, acc);
 }
 // out = dy * act'(y) AND db[c] += sum of it, one pass (UPPos backward: the masked gradient feeds the upsampling's adjoint, its channel
 // sums are the bias gradient).  Block = (channel c, sample b, chunk of the plane); float4 streams, inner % 4 == 0.
 __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, float* __restrict__ out,
-                                                          float* db, int C, int64_t inner4) {
+                                                          float* db, int C, int64_t inner4, DetWs ws) {
   __shared__ float red[16];
   const int c = blockIdx.x, b = blockIdx.y;
   const int64_t base = ((int64_t)b * C + c) * inner4;
@@ -416,6 +490,16 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restri
     acc += (r.x + r.y) + (r.z + r.w);
   }
   acc = block_sum(acc, red);
+  if (ws.counter) {                                    // group = the gridDim.y * gridDim.z workgroups of channel c; ws.part = [C][B][chunks]
+    const unsigned per = gridDim.y * gridDim.z;
+    if (threadIdx.x == 0) ws.part[(size_t)c * per + blockIdx.y * gridDim.z + blockIdx.z] = acc;
+    if (det_last_block(ws.counter + c, per) && threadIdx.x == 0) {
+      float sacc = 0.f;
+      for (unsigned k = 0; k < per; ++k) sacc += det_load(ws.part + (size_t)c * per + k);
+      db[c] += sacc;
+    }
+    return;
+  }
   if (threadIdx.x == 0) atomicAdd(db + c, acc);
 }
 // out = dy * act'(y) (y = saved post-activation tensor); float4 streams
@@ -500,9 +584,11 @@ extern "C" int p2i_attn_bwd(const float* x, const float* w0, const float* b0, co
   P2I_REQUIRE(T == 8 || T == 16 || T == 32, "AttentionBlock kernels exist for T in {8, 16, 32}");
   const dim3 grid(ceil_div(HW, 256), B);
   hipStream_t s = (hipStream_t)stream;
-  if (T == 16) P2I_LAUNCH(attn_bwd_kernel<16>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW);
-  else if (T == 32) P2I_LAUNCH(attn_bwd_kernel<32>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW);
-  else P2I_LAUNCH(attn_bwd_kernel<8>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW);
+  const size_t nblk = (size_t)grid.x * grid.y;
+  const DetWs ws = det_take(nblk * (1 + 2 * (size_t)(T * T + T)), 1);
+  if (T == 16) P2I_LAUNCH(attn_bwd_kernel<16>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW, ws);
+  else if (T == 32) P2I_LAUNCH(attn_bwd_kernel<32>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW, ws);
+  else P2I_LAUNCH(attn_bwd_kernel<8>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW, ws);
   return launch_status();
 }
 extern "C" int p2i_pooldup_fwd(const float* x, float* y, int B, int C, int H, int W, void* stream) {
@@ -546,8 +632,9 @@ extern "C" int p2i_upmod_bwd(const float* x, const float* pos, const float* du, 
   const int BC = B * C;
   if (dpos) {
     const int chunk = 16;
-    P2I_LAUNCH(upmod_bwd_pos_kernel, dim3(ceil_div(4 * S * S2w, 256), ceil_div(BC, chunk)), dim3(256), 0, s, x, pos, du, dpos,
-                       BC, S, S2w, chunk);
+    const dim3 gp(ceil_div(4 * S * S2w, 256), ceil_div(BC, chunk));
+    const DetWs ws = det_take((size_t)gp.x * 256 * gp.y, (int)gp.x);
+    P2I_LAUNCH(upmod_bwd_pos_kernel, gp, dim3(256), 0, s, x, pos, du, dpos, BC, S, S2w, chunk, ws);
   }
   if (dx) {
     {
@@ -571,7 +658,9 @@ extern "C" int p2i_dtail_bwd(const float* out2d, const float* alpha2d, const flo
   P2I_REQUIRE(out2d && alpha2d && dfused, "null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int n = B * H2 * W2;
-  P2I_LAUNCH(dtail_bwd2_kernel, dim3(min(ceil_div(n, 256), 64)), dim3(256), 0, s, out2d, alpha2d, dfused, dout2d, dalpha2d, n);
+  const int nb2 = min(ceil_div(n, 256), 64);
+  const DetWs ws = dalpha2d ? det_take((size_t)nb2, 1) : DetWs{nullptr, nullptr};
+  P2I_LAUNCH(dtail_bwd2_kernel, dim3(nb2), dim3(256), 0, s, out2d, alpha2d, dfused, dout2d, dalpha2d, n, ws);
   if (dout3d)
     P2I_LAUNCH(dtail_bwd3_kernel, dim3(ceil_div(B * H3 * W3, 256)), dim3(256), 0, s, dfused, dout3d, B, H2, W2, T3, H3, W3);
   return launch_status();
@@ -582,7 +671,8 @@ extern "C" int p2i_bias_grad(const float* dy, const float* y_act, int act, float
   int chunks = (int)((total + 16383) / 16384);
   if (chunks > 64) chunks = 64;
   if (chunks < 1) chunks = 1;
-  P2I_LAUNCH(bias_grad_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dy, y_act, act, db, B, C, inner);
+  const DetWs ws = det_take((size_t)C * chunks, C);
+  P2I_LAUNCH(bias_grad_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dy, y_act, act, db, B, C, inner, ws);
   return launch_status();
 }
 extern "C" int p2i_act_bwd(const float* dy, const float* y, int act, float* out, int64_t n, void* stream) {
@@ -595,7 +685,8 @@ extern "C" int p2i_act_bwd_bias(const float* dy, const float* y, int act, float*
   P2I_REQUIRE((inner & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) & 15) == 0, "inner % 4 and 16-byte alignment");
   int chunks = (int)((inner / 4 + 2047) / 2048);
   if (chunks > 16) chunks = 16;
-  P2I_LAUNCH(act_bwd_bias_kernel, dim3(C, B, chunks), dim3(256), 0, (hipStream_t)stream, dy, y, act, out, db, C, inner / 4);
+  const DetWs ws = det_take((size_t)C * B * chunks, C);
+  P2I_LAUNCH(act_bwd_bias_kernel, dim3(C, B, chunks), dim3(256), 0, (hipStream_t)stream, dy, y, act, out, db, C, inner / 4, ws);
   return launch_status();
 }
 extern "C" int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stream) {

@@ -662,6 +662,80 @@ __global__ __launch_bounds__(256) void idw_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// ---- deterministic backward (a scratch registered with p2i_det_workspace): the same scatter in 64-bit FIXED POINT.  Integer addition
+// is associative, so the order in which the atomics arrive no longer matters.  scale = 2^k with k chosen from max |dout| of the call
+// (idw_absmax_kernel: an integer max over the float bit patterns, order-free too) so that the sum of all 4 Q contributions of a
+// sample stays below 2^61: a contribution g * w (rounded to float as before) times 2^k is converted exactly unless it is smaller than
+// 2^-41 of the largest -- more accurate than the float atomics it replaces.  ctl[0] = bits of max |dout|, ctl[1] = ticket of the
+// last kernel (both zero between calls).
+__global__ __launch_bounds__(256) void idw_absmax_kernel(const float* __restrict__ dout, size_t n, unsigned* ctl) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(dout[i]));
+  m = block_max(m, red);
+  if (threadIdx.x == 0 && m > 0.f) atomicMax(ctl, __float_as_uint(m));
+}
+__device__ __forceinline__ int idw_fix_exp(unsigned maxbits, int Q) {
+  if (maxbits == 0u) return 0;
+  const int e = (int)((maxbits >> 23) & 0xffu) - 127;                // max |dout| < 2^(e + 1)
+  int lq = 2;                                                        // ceil(log2(4 Q))
+  while ((1ll << lq) < 4ll * Q) ++lq;
+  int k = 61 - (e + 1) - lq;
+  return k > 120 ? 120 : (k < -120 ? -120 : k);
+}
+__global__ __launch_bounds__(256) void idw_bwd_fix_kernel(const float* __restrict__ dout, const int32_t* __restrict__ pt_count,
+                                                         const int32_t* __restrict__ sel_idx, const float* __restrict__ sel_w,
+                                                         unsigned long long* acc64, const unsigned* __restrict__ ctl, int Q, int chunk) {
+  extern __shared__ unsigned long long accl[];          // [IDW_LDS_PTS]
+  const int b = blockIdx.y;
+  const int N = pt_count[b];
+  if (N < 4) return;
+  const float S = ldexpf(1.f, idw_fix_exp(ctl[0], Q));
+  const bool use_lds = N <= IDW_LDS_PTS;
+  if (use_lds) {
+    for (int j = threadIdx.x; j < N; j += blockDim.x) accl[j] = 0ull;
+    __syncthreads();
+  }
+  unsigned long long* ga = acc64 + (size_t)b * Q;
+  const int q0 = blockIdx.x * chunk, q1 = min(Q, q0 + chunk);
+  for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
+    const size_t i = (size_t)b * Q + q;
+    const float g = dout[i];
+    if (g == 0.f) continue;
+    const int4 id = *reinterpret_cast<const int4*>(sel_idx + i * 4);
+    const float4 w = *reinterpret_cast<const float4*>(sel_w + i * 4);
+    const unsigned long long c0 = (unsigned long long)__float2ll_rn(g * w.x * S), c1 = (unsigned long long)__float2ll_rn(g * w.y * S);
+    const unsigned long long c2 = (unsigned long long)__float2ll_rn(g * w.z * S), c3 = (unsigned long long)__float2ll_rn(g * w.w * S);
+    if (use_lds) {
+      atomicAdd(&accl[id.x], c0); atomicAdd(&accl[id.y], c1); atomicAdd(&accl[id.z], c2); atomicAdd(&accl[id.w], c3);
+    } else {
+      atomicAdd(ga + id.x, c0); atomicAdd(ga + id.y, c1); atomicAdd(ga + id.z, c2); atomicAdd(ga + id.w, c3);
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      const unsigned long long v = accl[j];
+      if (v != 0ull) atomicAdd(ga + j, v);
+    }
+  }
+}
+// d vals[pt_pos[j]] = fixed-point sum / scale; the last workgroup clears the control words for the next call
+__global__ __launch_bounds__(256) void idw_bwd_fix_finish_kernel(const unsigned long long* __restrict__ acc64, const int32_t* __restrict__ pt_pos,
+                                                                const int32_t* __restrict__ pt_count, float* dvals, unsigned* ctl, int Q) {
+  const int b = blockIdx.y;
+  const int N = pt_count[b];
+  const int k = idw_fix_exp(ctl[0], Q);
+  if (N >= 4) {
+    const int32_t* pp = pt_pos + (size_t)b * Q;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+      const long long v = (long long)acc64[(size_t)b * Q + j];
+      dvals[(size_t)b * Q + pp[j]] = (float)ldexp((double)v, -k);
+    }
+  }
+  if (det_last_block(ctl + 1, gridDim.x * gridDim.y) && threadIdx.x == 0) ctl[0] = 0u;
+}
+
 }  // namespace p2i
 using namespace p2i;
 
@@ -738,7 +812,23 @@ extern "C" int p2i_idw_bwd(const float* dout, const int32_t* pt_pos, const int32
   const size_t total = (size_t)B * Q;
   (void)p2i::memset_async(dvals_src, 0, sizeof(float) * total, (hipStream_t)stream);
   const int chunk = 4096;
-  P2I_LAUNCH(idw_bwd_kernel, dim3(ceil_div(Q, chunk), B), dim3(256), 0, (hipStream_t)stream, dout, pt_pos, pt_count, sel_idx,
-                     sel_w, dvals_src, Q, chunk);
+  hipStream_t s = (hipStream_t)stream;
+  // deterministic mode: 8 bytes of fixed-point accumulator per voxel slot (a sample has at most Q points) from the registered scratch
+  const DetWs ws = det_take(2 * total + 64, 2);
+  if (ws.counter != nullptr && (reinterpret_cast<uintptr_t>(ws.part) & 7) == 0) {
+    unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(ws.part);
+    (void)p2i::memset_async(acc64, 0, sizeof(unsigned long long) * total, s);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)idw_bwd_fix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr_set = true;
+    }
+    P2I_LAUNCH(idw_absmax_kernel, dim3(256), dim3(256), 0, s, dout, total, ws.counter);
+    P2I_LAUNCH(idw_bwd_fix_kernel, dim3(ceil_div(Q, chunk), B), dim3(256), sizeof(unsigned long long) * IDW_LDS_PTS, s, dout, pt_count, sel_idx,
+               sel_w, acc64, ws.counter, Q, chunk);
+    P2I_LAUNCH(idw_bwd_fix_finish_kernel, dim3(16, B), dim3(256), 0, s, acc64, pt_pos, pt_count, dvals_src, ws.counter, Q);
+    return launch_status();
+  }
+  P2I_LAUNCH(idw_bwd_kernel, dim3(ceil_div(Q, chunk), B), dim3(256), 0, s, dout, pt_pos, pt_count, sel_idx, sel_w, dvals_src, Q, chunk);
   return launch_status();
 }

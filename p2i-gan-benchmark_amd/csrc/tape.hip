@@ -1,6 +1,7 @@
 // Launch tape (tape.h): recording, replay and the stream-dependency primitives of the C ABI.  Host code only.
 #include "common.h"
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 namespace p2i {
@@ -99,8 +100,41 @@ static int event_op(int kind, int slot, hipStream_t s, bool record_it) {
   return P2I_OK;
 }
 
+// ---- scratch of the deterministic reductions (common.h: det_last_block).  Registered once by the caller (caller-owned device
+// memory); every call that needs scratch takes the next piece of the ring.  Pieces are reused only after the ring has wrapped:
+// with the ring sized for many calls (the Python binding registers 64 MB for ~5 MB per train step) the kernels that used a piece
+// before have long finished -- the steps of a training run are chained through the weights.
+// (process-wide, one GPU per process: autograd runs a user's loss.backward() on its own thread, which must find the scratch too)
+static float* g_det_part = nullptr;
+static size_t g_det_floats = 0, g_det_pos = 0;
+static unsigned* g_det_cnt = nullptr;
+static int g_det_ncnt = 0, g_det_cpos = 0;
+static std::mutex g_det_mu;
+
+DetWs det_take(size_t floats, int counters) {
+  DetWs w{nullptr, nullptr};
+  std::lock_guard<std::mutex> lock(g_det_mu);
+  floats = (floats + 63) & ~(size_t)63;
+  if (!g_det_part || floats > g_det_floats || counters > g_det_ncnt) return w;
+  if (g_det_pos + floats > g_det_floats) g_det_pos = 0;
+  if (g_det_cpos + counters > g_det_ncnt) g_det_cpos = 0;
+  w.part = g_det_part + g_det_pos;
+  w.counter = g_det_cnt + g_det_cpos;
+  g_det_pos += floats;
+  g_det_cpos += counters;
+  return w;
+}
+
 }  // namespace p2i
 using namespace p2i;
+
+extern "C" int p2i_det_workspace(float* part, int64_t part_floats, unsigned* counters, int n_counters) {
+  std::lock_guard<std::mutex> lock(g_det_mu);
+  if (part == nullptr) { g_det_part = nullptr; g_det_floats = 0; g_det_cnt = nullptr; g_det_ncnt = 0; g_det_pos = 0; g_det_cpos = 0; return P2I_OK; }
+  P2I_REQUIRE(part_floats >= (1 << 16) && counters && n_counters >= 1024, "deterministic-reduction scratch too small");
+  g_det_part = part; g_det_floats = (size_t)part_floats; g_det_cnt = counters; g_det_ncnt = n_counters; g_det_pos = 0; g_det_cpos = 0;
+  return P2I_OK;
+}
 
 extern "C" int p2i_event_record(int slot, void* stream) { return event_op(OP_RECORD, slot, (hipStream_t)stream, true); }
 extern "C" int p2i_event_wait(int slot, void* stream) { return event_op(OP_WAIT, slot, (hipStream_t)stream, true); }

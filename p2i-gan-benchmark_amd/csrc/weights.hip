@@ -350,7 +350,7 @@ __global__ void pack_kernel(const float* __restrict__ w, int O, int I, int NT, c
   if (wp_d) wp_d[((size_t)tap * O + o) * pad32(I) + i] = v;
 }
 
-__global__ void unpack_dot_kernel(const float* __restrict__ dwp, const float* __restrict__ w, int O, int I, int NT, float* dot) {
+__global__ void unpack_dot_kernel(const float* __restrict__ dwp, const float* __restrict__ w, int O, int I, int NT, float* dot, DetWs ws) {
   __shared__ float red[16];
   float acc = 0.f;
   const int n = O * I * NT;
@@ -359,6 +359,15 @@ __global__ void unpack_dot_kernel(const float* __restrict__ dwp, const float* __
     acc += dwp[((size_t)tap * I + i) * pad32(O) + o] * w[idx];
   }
   acc = block_sum(acc, red);
+  if (ws.counter) {
+    if (threadIdx.x == 0) ws.part[blockIdx.x] = acc;
+    if (det_last_block(ws.counter, gridDim.x) && threadIdx.x == 0) {
+      float sacc = 0.f;
+      for (unsigned k = 0; k < gridDim.x; ++k) sacc += det_load(ws.part + k);
+      *dot = sacc;
+    }
+    return;
+  }
   if (threadIdx.x == 0) atomicAdd(dot, acc);
 }
 
@@ -554,7 +563,8 @@ extern "C" int p2i_weight_unpack_grad(const float* dwp_f, int O, int I, int ntap
   const int n = O * I * ntaps;
   if (sigma_ptr) {
     (void)p2i::memset_async(scratch, 0, sizeof(float), s);
-    P2I_LAUNCH(unpack_dot_kernel, dim3(min(ceil_div(n, 256), 256)), dim3(256), 0, s, dwp_f, w_orig, O, I, ntaps, scratch);
+    const int nbd = min(ceil_div(n, 256), 256);
+    P2I_LAUNCH(unpack_dot_kernel, dim3(nbd), dim3(256), 0, s, dwp_f, w_orig, O, I, ntaps, scratch, det_take((size_t)nbd, 1));
   }
   P2I_LAUNCH(unpack_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dwp_f, O, I, ntaps, sigma_ptr, scratch, u, v, dw);
   return launch_status();
@@ -662,7 +672,7 @@ __global__ void pack_batched_kernel(const PackBatch b) {
     if (b.d[L]) b.d[L][((size_t)tap * O + o) * pad32(I) + i] = v;
   }
 }
-__global__ void unpack_dot_batched_kernel(const PackBatch b) {
+__global__ void unpack_dot_batched_kernel(const PackBatch b, DetWs ws) {
   __shared__ float red[16];
   const int L = blockIdx.z, O = b.O[L], I = b.I[L], NT = b.NT[L];
   if (!b.div[L]) return;                              // plain unpack: no sigma term
@@ -673,6 +683,15 @@ __global__ void unpack_dot_batched_kernel(const PackBatch b) {
     acc += b.g[L][((size_t)tap * I + i) * pad32(O) + o] * b.w[L][idx];
   }
   acc = block_sum(acc, red);
+  if (ws.counter) {                                    // group = the gridDim.x workgroups of layer L; ws.part = [layers][gridDim.x]
+    if (threadIdx.x == 0) ws.part[(size_t)L * gridDim.x + blockIdx.x] = acc;
+    if (det_last_block(ws.counter + L, gridDim.x) && threadIdx.x == 0) {
+      float sacc = 0.f;
+      for (unsigned k = 0; k < gridDim.x; ++k) sacc += det_load(ws.part + (size_t)L * gridDim.x + k);
+      *b.dot[L] = sacc;
+    }
+    return;
+  }
   if (threadIdx.x == 0 && acc != 0.f) atomicAdd(b.dot[L], acc);
 }
 __global__ void unpack_batched_kernel(const PackBatch b) {
@@ -728,7 +747,9 @@ extern "C" int p2i_weight_unpack_grad_batched_acc(const float* const* dwp_f, con
   const int blocks = ceil_div(maxn, 256);
   if (any_sigma) {
     (void)p2i::memset_async(dots, 0, sizeof(float) * n, s);
-    P2I_LAUNCH(unpack_dot_batched_kernel, dim3(blocks > 128 ? 128 : blocks, 1, n), dim3(256), 0, s, b);
+    const int nbd = blocks > 128 ? 128 : blocks;
+    const DetWs ws = det_take((size_t)nbd * n, n);
+    P2I_LAUNCH(unpack_dot_batched_kernel, dim3(nbd, 1, n), dim3(256), 0, s, b, ws);
   }
   P2I_LAUNCH(unpack_batched_kernel, dim3(blocks > 512 ? 512 : blocks, 1, n), dim3(256), 0, s, b);
   return launch_status();

@@ -37,13 +37,17 @@ struct WgradGeom {
   unsigned mg_ewq4;
   float* partial;        // != null: workgroup blockIdx.x STORES its partial tile to partial + blockIdx.x * pstride (same
   long long pstride;     // [tap][c][o] indexing as dwp) instead of atomically adding it; wgrad_reduce_kernel sums the slices
+  long long bias_off;    // slice mode with a fused bias gradient: the slice's bias row starts here (behind the tile)
 };
 
 // dwp[i] += sum_s partial[s][i] (o < Co; the padded columns stay untouched).  Replaces ns-way float atomics on every
 // element (1.3 TB/s chip-wide, ~29 us for the 37.7 MB of a 3x3 C->C layer) by one coalesced write + read of the slices,
 // and makes the weight gradient bit-reproducible from run to run.
+// Round 4: a slice may carry a bias row behind its [tap][c][o] tile (floats [4 nmain4, 4 n4) of the slice: the per-channel sums of dy
+// the kernel's bias-fusing workgroups stored); those elements are added to dbias instead of dwp -- the bias gradient is then summed
+// in slice order like the weights (it was ns float atomics per channel).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int ns, long long pstride, int n4, int Co,
-                                                           int CoPad, int lsg, float* __restrict__ dwp) {
+                                                           int CoPad, int lsg, float* __restrict__ dwp, int nmain4, float* __restrict__ dbias) {
   // 256 threads = (256 >> lsg) float4 columns x (1 << lsg) slice groups; group q sums slices q, q + SG, ... (4 loads in flight)
   __shared__ float4 red[256];
   const int SG = 1 << lsg, ncol = 256 >> lsg;
@@ -74,9 +78,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const float4 v = red[k * ncol + col];
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
-      const int o = (i * 4) % CoPad;                   // CoPad % 4 == 0: a float4 never straddles rows
+      const int o = i < nmain4 ? (i * 4) % CoPad : (i - nmain4) * 4;      // CoPad % 4 == 0: a float4 never straddles rows
       if (o < Co) {
-        float* d = dwp + (size_t)i * 4;
+        float* d = i < nmain4 ? dwp + (size_t)i * 4 : dbias + (size_t)(i - nmain4) * 4;
         d[0] += acc.x;                                 // the padded columns stay as they are
         if (o + 1 < Co) d[1] += acc.y;
         if (o + 2 < Co) d[2] += acc.z;
@@ -586,7 +590,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradGeom g) {
     bsum += __shfl_xor(bsum, 2, 64);
     bsum += __shfl_xor(bsum, 4, 64);
     const int oc = o0 + (tid >> 3);
-    if ((tid & 7) == 0 && oc < g.Co) atomicAdd(g.dbias + oc, bsum);
+    if ((tid & 7) == 0 && oc < g.Co) {
+      if (g.partial != nullptr) g.partial[(long long)blockIdx.x * g.pstride + g.bias_off + oc] = bsum;     // summed in slice order by wgrad_reduce_kernel
+      else atomicAdd(g.dbias + oc, bsum);
+    }
   }
   // combine the KS pixel-range partial sums inside the workgroup (through LDS, 4 taps at a time) so that only
   // one wave per (c tile, o tile) issues the global float atomics: they run at ~1.3 TB/s chip-wide and would
@@ -657,15 +664,19 @@ extern "C" int p2i_wgrad_last_plan(int* out4) {
 }
 
 // dwp[i] += sum over the ns slices of a launch
-static int launch_wgrad_reduce(const float* ws, int ns, long long slice, int Co, int CoPad, float* dwp, hipStream_t s) {
-  const int n4 = (int)(slice / 4);
+// slice: floats of one slice's [tap][c][o] tile; dbias != null: each slice holds CoPad more floats (its bias row), pstride = slice + CoPad
+static int launch_wgrad_reduce(const float* ws, int ns, long long slice, int Co, int CoPad, float* dwp, hipStream_t s, float* dbias = nullptr,
+                               long long pstride = 0) {
+  if (pstride == 0) pstride = slice;
+  const int nmain4 = (int)(slice / 4);
+  const int n4 = nmain4 + (dbias ? CoPad / 4 : 0);
   // enough threads to stream the ns * slice floats at HBM rate: split the slices over up to 8 groups while the
   // columns alone give fewer than ~2 blocks per CU
   int lsg = 0;
   while (lsg < 3 && (2 << lsg) <= ns && (n4 >> (8 - lsg)) < 512) ++lsg;
   const int ncol = 256 >> lsg;
   const int blocks = (n4 + ncol - 1) / ncol;
-  P2I_LAUNCH(wgrad_reduce_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, s, ws, ns, slice, n4, Co, CoPad, lsg, dwp);
+  P2I_LAUNCH(wgrad_reduce_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, s, ws, ns, pstride, n4, Co, CoPad, lsg, dwp, nmain4, dbias);
   return launch_status();
 }
 
@@ -702,7 +713,8 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
     if (rc != 1) {
       if (rc) return rc;
       g_wgrad_plan[0] = 3; g_wgrad_plan[1] = 9 * d->kt; g_wgrad_plan[2] = 1; g_wgrad_plan[3] = 64;
-      if (ns6 >= 2) return launch_wgrad_reduce(g_wgrad_ws, ns6, slice6, d->Cout, (d->Cout + 31) / 32 * 32, dwp, s);
+      if (ns6 >= 2) return launch_wgrad_reduce(g_wgrad_ws, ns6, slice6, d->Cout, (d->Cout + 31) / 32 * 32, dwp, s, dbias,
+                                               slice6 + (dbias ? (d->Cout + 31) / 32 * 32 : 0));
       return P2I_OK;
     }
   }
@@ -825,13 +837,15 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
         if (ga.dbias) bias_fused = true;
         // slice mode: ns >= 2 partial tiles per output element and a scratch that holds all ns slices of this launch
         const long long slice = (long long)g.tpg * d->Cin * g.CoPad;
-        const bool sliced = ns >= 2 && g_wgrad_ws != nullptr && slice * ns <= g_wgrad_ws_floats && slice < (1ll << 31);
+        const long long pstr = slice + (ga.dbias ? g.CoPad : 0);          // (+ the slice's bias row)
+        const bool sliced = ns >= 2 && g_wgrad_ws != nullptr && pstr * ns <= g_wgrad_ws_floats && slice < (1ll << 31);
         ga.partial = sliced ? g_wgrad_ws : nullptr;
-        ga.pstride = slice;
+        ga.pstride = pstr;
+        ga.bias_off = slice;
         P2I_LAUNCH(kern, dim3(ns, ncb, nco), dim3(512), lds2, s, ga);
         if (int e = launch_status()) return e;
         if (sliced)
-          if (int e = launch_wgrad_reduce(g_wgrad_ws, ns, slice, d->Cout, g.CoPad, ga.dwp, s)) return e;
+          if (int e = launch_wgrad_reduce(g_wgrad_ws, ns, slice, d->Cout, g.CoPad, ga.dwp, s, ga.dbias, pstr)) return e;
       }
     }
   }

@@ -46,7 +46,8 @@ struct Wx6Geom {
   float* dwp;            // packed grad [kt * 9][Cx][CoPad]
   float* partial;        // != null: slice s stores to partial + s * pstride (same indexing), wgrad_reduce_kernel sums
   float* dbias;          // != null: db[o] += sum of dy (added atomically by the channel-block-0 / t-slice-0 workgroups)
-  long long pstride;
+  long long pstride;     // floats from one slice to the next (the tile, + CoPad for the slice's bias row when dbias is given)
+  long long bias_off;    // where a slice's bias row starts
   int B, Cx, Co, CoPad, H, W;
   int nth, ntw, ntiles;
   unsigned x_bytes, dy_bytes;
@@ -330,7 +331,10 @@ __global__ __launch_bounds__(512) void wgrad_x6_kernel(const Wx6Geom g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float sj = wave_sum(bsum[j]);
-      if (lane == 0) atomicAdd(g.dbias + ob * 64 + y_chunk * 8 + j, sj);
+      if (lane == 0) {
+        if (g.partial) g.partial[(size_t)blockIdx.x * g.pstride + g.bias_off + ob * 64 + y_chunk * 8 + j] = sj;   // summed in slice order by wgrad_reduce_kernel
+        else atomicAdd(g.dbias + ob * 64 + y_chunk * 8 + j, sj);
+      }
     }
   }
   auto emit = [&](auto&& put) {
@@ -471,7 +475,10 @@ __global__ __launch_bounds__(512) void wgrad_x6p_kernel(const Wx6Geom g) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float sj = wave_sum(bsum[it][j]);
-          if (lane == 0) atomicAdd(g.dbias + ob * 64 + (((p + 256 * it) >> 6)) * 8 + j, sj);
+          if (lane == 0) {
+            if (g.partial) g.partial[(size_t)blockIdx.x * g.pstride + g.bias_off + ob * 64 + (((p + 256 * it) >> 6)) * 8 + j] = sj;
+            else atomicAdd(g.dbias + ob * 64 + (((p + 256 * it) >> 6)) * 8 + j, sj);
+          }
         }
     }
     return;
@@ -569,10 +576,12 @@ int run_wgrad_x6(const p2i_conv_desc* d, const float* x, const float* dy, float*
   if (ns < 1) ns = 1;
   if (ns > g.ntiles) ns = g.ntiles;
   const long long slice = 9ll * d->kt * d->Cin * g.CoPad;
-  const bool sliced = ns >= 2 && ws != nullptr && slice * ns <= ws_floats && slice < (1ll << 31);
+  const long long pstr = slice + (dbias ? g.CoPad : 0);                // (+ the slice's bias row)
+  const bool sliced = ns >= 2 && ws != nullptr && pstr * ns <= ws_floats && slice < (1ll << 31);
   if (ns >= 2 && !sliced) return 1;                    // no scratch for the slices: the f32 kernel's atomic path
   g.partial = sliced ? ws : nullptr;
-  g.pstride = slice;
+  g.pstride = pstr;
+  g.bias_off = slice;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wgrad_x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

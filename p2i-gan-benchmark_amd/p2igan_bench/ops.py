@@ -227,7 +227,7 @@ def _wgrad_scratch(device):
     key = (device.index, _stream())
     buf = _WGRAD_WS.get(key)
     if buf is None:
-        buf = torch.empty(256 * 9 * 64 * 64 + 1024, device=device, dtype=torch.float32)
+        buf = torch.empty(256 * (9 * 64 * 64 + 512) + 1024, device=device, dtype=torch.float32)      # slices + their bias rows
         _WGRAD_WS[key] = buf
     return buf
 
@@ -304,6 +304,26 @@ def fork(src_stream: int, dst_stream: int):
     slot = _next_slot()
     _hip.check(lib.p2i_event_record(slot, src_stream), "p2i_event_record")
     _hip.check(lib.p2i_event_wait(slot, dst_stream), "p2i_event_wait")
+
+
+# Run-to-run reproducibility: the scratch of the library's deterministic reductions (include/p2i_hip.h, p2i_det_workspace), registered
+# once per process and device at the first backward op.  P2I_DETERMINISTIC=0 keeps the float atomics (A/B runs).
+_DET = {}
+
+
+def det_ready(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key in _DET:
+        return
+    if _os.environ.get("P2I_DETERMINISTIC", "1") == "0":
+        _DET[key] = None
+        return
+    mb = int(_os.environ.get("P2I_DET_SCRATCH_MB", "128"))
+    part = torch.empty(mb << 18, device=device, dtype=torch.float32)
+    cnt = torch.zeros(8192, device=device, dtype=torch.int32)
+    torch.cuda.current_stream(device).synchronize()          # the counters are zero before any kernel of any stream can use them
+    _hip.check(_hip.load().p2i_det_workspace(part.data_ptr(), part.numel(), cnt.data_ptr(), cnt.numel()), "p2i_det_workspace")
+    _DET[key] = (part, cnt)
 
 
 def pad32(n: int) -> int:
@@ -450,6 +470,7 @@ def conv_wgrad(spec: ConvSpec, x, dy, y_act=None, act=ACT_NONE, want_bias=False,
     """Packed weight gradient dwp_f [ntaps][cin][pad32(cout)] (+ bias gradient).  db_out: caller-owned (cout,) tensor the bias
     gradient is ADDED to (e.g. the parameter's view of the flat gradient buffer)."""
     lib = _hip.load()
+    det_ready(x.device)
     b, c, t, h, w = _dims5(x)
     to, ho, wo = spec.out_dims(t, h, w)
     eshape = (b, spec.cout, ho, wo) if x.dim() == 4 else (b, spec.cout, to, ho, wo)
@@ -628,6 +649,7 @@ def weight_unpack_grad_batched(dwps, likes, w_origs=None, sigmas=None, us=None, 
     outs: caller-owned targets (numel must match); accumulate: dw += instead of dw = (second backward of a D step)."""
     import ctypes
     lib = _hip.load()
+    det_ready(dwps[0].device)
     n = len(dwps)
     Os, Is, NTs = [l.shape[0] for l in likes], [l.shape[1] for l in likes], [l.shape[2] for l in likes]
     for g, o, i, nt in zip(dwps, Os, Is, NTs):
@@ -655,6 +677,7 @@ def weight_unpack_grad_batched(dwps, likes, w_origs=None, sigmas=None, us=None, 
 
 def weight_unpack_grad(dwp_f, like, w_orig=None, sigma=None, u=None, v=None, out=None):
     lib = _hip.load()
+    det_ready(dwp_f.device)
     O, I = like.shape[0], like.shape[1]
     nt = like[0, 0].numel()
     if tuple(dwp_f.shape) != (nt, I, pad32(O)):
@@ -748,6 +771,7 @@ def attn_fwd(x, w0, b0, w1, b1):
 def attn_bwd(x, w0, b0, w1, b1, dout, out=None):
     """out: four caller-owned, ZEROED targets shaped like (w0, b0, w1, b1) (the kernel adds atomically)."""
     lib = _hip.load()
+    det_ready(x.device)
     B, T, H, W = x.shape
     if dout.shape != x.shape:
         raise RuntimeError("attn_bwd: dout shape mismatch")
@@ -829,6 +853,7 @@ def idw_fwd(vals_src, mask, tau=0.05, save=True, _amb_out=None):
 
 def idw_bwd(dout, saved):
     lib = _hip.load()
+    det_ready(dout.device)
     B, T, H, W = dout.shape
     pt_pos, pt_count, sel_idx, sel_w = saved
     dvals = torch.empty_like(dout)
@@ -879,6 +904,7 @@ def upmod_fwd(x, pos, bias=None, act=ACT_NONE):
 def upmod_bwd(x, pos, du, need_dx=True, dpos_out=None):
     """dpos_out: caller-owned ZEROED target shaped like pos (the kernel adds atomically)."""
     lib = _hip.load()
+    det_ready(x.device)
     B, Cc, Sh, Sw = x.shape
     if tuple(du.shape) != (B, Cc, 2 * Sh, 2 * Sw):
         raise RuntimeError("upmod_bwd: du shape mismatch")
@@ -908,6 +934,7 @@ def dtail_fwd(out2d, out3d, alpha2d):
 def dtail_bwd(out2d, out3d_shape, alpha2d, dfused, need_alpha=True, da_out=None):
     """da_out: caller-owned (1,) target the alpha2d gradient is ADDED to."""
     lib = _hip.load()
+    det_ready(out2d.device)
     B, _, H2, W2 = out2d.shape
     _, _, T3, H3, W3 = out3d_shape
     d2 = torch.empty_like(out2d)
@@ -1036,6 +1063,7 @@ def act_bwd(dy, y, act):
 def act_bwd_bias(dy, y, act, db_out=None):
     """(dy * act'(y), its per-channel sum) in one pass; db_out: caller-owned ZEROED (C,) target the kernel adds into."""
     lib = _hip.load()
+    det_ready(dy.device)
     B, Cc = dy.shape[0], dy.shape[1]
     inner = dy[0, 0].numel()
     if inner % 4:
@@ -1051,6 +1079,7 @@ def act_bwd_bias(dy, y, act, db_out=None):
 def bias_grad(dy, y_act=None, act=ACT_NONE, out=None):
     """out: caller-owned ZEROED (Cc,) target the kernel adds into."""
     lib = _hip.load()
+    det_ready(dy.device)
     B, Cc = dy.shape[0], dy.shape[1]
     inner = dy[0, 0].numel()
     if out is not None and out.numel() != Cc:
