@@ -193,7 +193,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (c < g.Cx && o < g.Co) atomicAdd(g.dwp + ((size_t)((tap0 + t) * g.Cx + c)) * g.CoPad + o, acc[t][r]);
+        if (c < g.Cx && o < g.Co) {
+          const size_t e = ((size_t)((tap0 + t) * g.Cx + c)) * g.CoPad + o;
+          if (g.partial != nullptr) g.partial[(long long)blockIdx.x * g.pstride + e] = acc[t][r];     // this pixel-split's slice (wgrad_reduce_kernel sums)
+          else atomicAdd(g.dwp + e, acc[t][r]);
+        }
       }
     }
   }
@@ -849,16 +853,30 @@ extern "C" int p2i_conv_wgrad(const p2i_conv_desc* d, const float* x, const floa
       }
     }
   }
-  if (!use_dma)
-  for (int a = 0; a < d->kt; ++a) {   // one launch per kt slice (the patch's t origin differs per slice)
-    WgradGeom ga = g;
-    ga.bT = a - d->pt;
-    ga.ntaps = g.tpg;
-    ga.tpg = g.tpg;
-    ga.dwp = dwp + (size_t)a * g.tpg * d->Cin * g.CoPad;
-    for (int i = 0; i < g.tpg; ++i) ga.tap_off[i] = g.tap_off[a * g.tpg + i];
-    P2I_LAUNCH(wgrad_kernel<NPIX>, dim3(nsplit, ncx, nco), dim3(256), lds, s, ga);
-    if (int e = launch_status()) return e;
+  if (!use_dma) {
+    // slice mode here too (round 4: maps narrower than 8 columns -- the deep levels of small crops -- took nsplit-way float atomics):
+    // as many pixel splits as the scratch holds slices for, each storing its tile, summed in split order
+    const long long slice = (long long)g.tpg * d->Cin * g.CoPad;
+    if (g_wgrad_ws != nullptr && nsplit >= 2 && slice < (1ll << 31)) {
+      const long long fit = g_wgrad_ws_floats / slice;
+      if (fit < nsplit) nsplit = fit >= 2 ? (int)fit : 1;
+    }
+    const bool sliced = nsplit >= 2 && g_wgrad_ws != nullptr && slice * nsplit <= g_wgrad_ws_floats && slice < (1ll << 31);
+    for (int a = 0; a < d->kt; ++a) {   // one launch per kt slice (the patch's t origin differs per slice)
+      WgradGeom ga = g;
+      ga.nsplit = nsplit;
+      ga.bT = a - d->pt;
+      ga.ntaps = g.tpg;
+      ga.tpg = g.tpg;
+      ga.dwp = dwp + (size_t)a * g.tpg * d->Cin * g.CoPad;
+      ga.partial = sliced ? g_wgrad_ws : nullptr;
+      ga.pstride = slice;
+      for (int i = 0; i < g.tpg; ++i) ga.tap_off[i] = g.tap_off[a * g.tpg + i];
+      P2I_LAUNCH(wgrad_kernel<NPIX>, dim3(nsplit, ncx, nco), dim3(256), lds, s, ga);
+      if (int e = launch_status()) return e;
+      if (sliced)
+        if (int e = launch_wgrad_reduce(g_wgrad_ws, nsplit, slice, d->Cout, g.CoPad, ga.dwp, s)) return e;
+    }
   }
   if (dbias && !bias_fused) return p2i_bias_grad(dy, y_act, act, dbias, d->B, d->Cout, (int64_t)d->To * d->Ho * d->Wo, stream);
   return P2I_OK;
