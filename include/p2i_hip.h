@@ -345,9 +345,10 @@ int p2i_act_bwd_bias(const float* dy, const float* y, int act, float* out, float
 /* ---- Run-to-run reproducibility (round 4).  The step's small cross-workgroup sums (bias / position / attention-weight / alpha
  * gradients, spectral-norm dot products, the 1 -> 32 layer's weight gradient, the IDW backward scatter) are float atomics by
  * default: their order, hence their rounding, changes from run to run (the reference on CPU is deterministic).  With a scratch
- * registered here they are summed in a fixed order instead (last-workgroup-done, no extra launch; the IDW scatter in 64-bit fixed
- * point).  part: >= 65 536 floats (the Python binding gives 64 MB: pieces are handed out round-robin and must not be reused
- * while an earlier kernel may still run); counters: >= 1 024 unsigned, ZERO-initialised by the caller, left zero by every kernel.
+ * registered here they are summed in a fixed order instead (the workgroups store their partials, one more small launch adds them
+ * in workgroup order; bias gradients ride in the weight-gradient slices; the IDW scatter runs in 64-bit fixed point).  part: >= 65 536
+ * floats (the Python binding gives 128 MB: pieces are handed out round-robin and must not be reused while an earlier kernel may
+ * still run); counters: >= 1 024 unsigned, zero-initialised (reserved).
  * Process-wide (one GPU per process); part == NULL unregisters. */
 int p2i_det_workspace(float* part, int64_t part_floats, unsigned* counters, int n_counters);
 int p2i_event_record(int slot, void* stream);

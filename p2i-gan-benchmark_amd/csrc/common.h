@@ -93,34 +93,22 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return s;
 }
 
-// ---- deterministic cross-workgroup sums ("last block done", no second launch, no spinning).  The small reductions of the step
-// (bias / position / attention-weight / alpha gradients, a few dot products) used to end in float atomics, whose order -- hence
-// whose rounding -- changes from run to run.  With a caller-owned scratch they are summed in a FIXED order instead: every workgroup of
-// a group stores its partial, makes it visible (__threadfence) and takes a ticket from the group's counter; the workgroup that draws
-// the last ticket adds the group's partials in workgroup order and resets the counter to 0 for the next call on the stream (the
-// counters must be zero before the first use; kernels of one stream never overlap, so one counter array per stream serves every
-// call).  Returns true, in every thread of that last workgroup, once all partials of the group are visible.
+// ---- deterministic cross-workgroup sums.  The small reductions of the step (bias / position / attention-weight / alpha gradients, a
+// few dot products) used to end in float atomics, whose order -- hence whose rounding -- changes from run to run.  With a caller-owned
+// scratch (p2i_det_workspace) they are summed in a FIXED order instead, in two stages: the kernel's workgroups STORE their partials,
+// det_reduce (one more small launch) adds them in workgroup order.  (First version, measured and dropped: the last workgroup to
+// finish added the partials inside the same launch.  Its __threadfence() is an L2 write-back on this multi-die part -- every workgroup
+// paid for flushing what the kernel had just written: act_bwd_bias 12 -> 126 us, the step +1.9 ms.)
 struct DetWs {
-  float* part;          // partial sums (layout: per kernel)
-  unsigned* counter;    // >= number of groups, zero-initialised, self-resetting
+  float* part;          // partial sums (layout: per kernel); nullptr: no scratch registered -> float atomics
+  unsigned* counter;    // (reserved)
 };
-__device__ __forceinline__ bool det_last_block(unsigned* counter, unsigned nblocks) {
-  __shared__ int det_last_;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned prev = atomicAdd(counter, 1u);
-    det_last_ = prev == nblocks - 1 ? 1 : 0;
-    if (det_last_) *counter = 0;
-  }
-  __syncthreads();
-  if (det_last_) __threadfence();
-  return det_last_ != 0;
-}
-// a partial written by another workgroup: bypass this CU's L1 (which is not coherent with the other CUs' stores)
-__device__ __forceinline__ float det_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // host: this call's share of the scratch registered with p2i_det_workspace ({nullptr, nullptr}: none registered, or too small --
 // the kernels then keep their float atomics)
 DetWs det_take(size_t floats, int counters);
+// out[g] += sum_{k < n} part[g * gs + k * ks] for g < groups, k ascending.  Up to four output segments: group g of segment i
+// (lengths seg_len, consecutive g) goes to seg_out[i][g - start_i].
+struct DetSegs { float* out[4]; int len[4]; };
+int det_reduce(const float* part, int groups, int n, long long gs, long long ks, const DetSegs& segs, hipStream_t s);
 
 }  // namespace p2i

@@ -446,36 +446,13 @@ __global__ __launch_bounds__(256) void c1_wgrad_mfma_kernel(const p2i_conv_desc 
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
   __syncthreads();
-  if (ws.counter) {
-    // deterministic: two levels of last-workgroup-done.  ws.part = [gridDim.x][28 x 32] workgroup partials, then [groups][28 x 32]
-    // group sums; groups of C1_DG consecutive workgroups; counters: one per group, then one for the groups.
-    constexpr int C1_DG = 16, PT = 28 * 32;
-    const unsigned nblk = gridDim.x, ngrp = (nblk + C1_DG - 1) / C1_DG, grp = blockIdx.x / C1_DG;
-    const unsigned gsz = min((unsigned)C1_DG, nblk - grp * C1_DG);
-    float* p1 = ws.part;
-    float* p2 = ws.part + (size_t)nblk * PT;
+  if (ws.part) {                                       // ws.part = [workgroups][28 x 32]: added in workgroup order by det_reduce
     if (wave == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = (red[r * 64 + lane] + red[(16 + r) * 64 + lane]) + (red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane]);
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (row < 28) p1[(size_t)blockIdx.x * PT + row * 32 + l31] = v;
-      }
-    }
-    if (!det_last_block(ws.counter + grp, gsz)) return;
-    for (int e = threadIdx.x; e < PT; e += 256) {
-      float sacc = 0.f;
-      for (unsigned k = 0; k < gsz; ++k) sacc += det_load(p1 + (size_t)(grp * C1_DG + k) * PT + e);
-      p2[(size_t)grp * PT + e] = sacc;
-    }
-    if (!det_last_block(ws.counter + ngrp, ngrp)) return;
-    for (int e = threadIdx.x; e < PT; e += 256) {
-      float sacc = 0.f;
-      for (unsigned k = 0; k < ngrp; ++k) sacc += det_load(p2 + (size_t)k * PT + e);
-      const int row = e >> 5, oc = e & 31;
-      if (oc < d.Cout) {
-        if (row < 27) dwp[row * 32 + oc] += sacc;
-        else if (dbias) dbias[oc] += sacc;
+        if (row < 28) ws.part[(size_t)blockIdx.x * (28 * 32) + row * 32 + l31] = v;
       }
     }
     return;
@@ -525,9 +502,10 @@ static int c1_wgrad_mfma(const p2i_conv_desc* d, const float* x, const float* dy
     attr_set = true;
   }
   const int grid = ntiles < 512 ? (int)ntiles : 512;
-  const int ngrp = (grid + 15) / 16;
-  const DetWs ws = det_take((size_t)(grid + ngrp) * 28 * 32, ngrp + 1);
+  const DetWs ws = det_take((size_t)grid * 28 * 32, 0);
   P2I_LAUNCH(c1_wgrad_mfma_kernel, dim3(grid), dim3(256), lds, s, *d, x, dy, dwp, dbias, nth, ntw, (int)ntiles, ws);
+  // taps x 32 columns (the columns >= Cout of the partials are zero: nothing of dy there), then the bias row
+  if (ws.part) return det_reduce(ws.part, 27 * 32 + (dbias ? d->Cout : 0), grid, 1, 28 * 32, DetSegs{{dwp, dbias, nullptr, nullptr}, {27 * 32, dbias ? d->Cout : 0, 0, 0}}, s);
   return launch_status();
 }
 

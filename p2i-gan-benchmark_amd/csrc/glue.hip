@@ -50,6 +50,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 // T-1), a fixed order inside the block, one global atomic per parameter and block at the end (blocks without an active pixel leave).
 constexpr int ATTN_LIST = 32;
 
+// Round 4: a workgroup walks SEVERAL 256-pixel chunks of its sample (grid.x chunks-strided) and keeps summing into the same
+// registers, so a launch ends with grid.x * B partial vectors instead of one per chunk (512 at B = 8): with a scratch (ws.part)
+// each workgroup stores its partial and det_reduce adds them in workgroup order -- deterministic, and a sum over a few dozen
+// vectors; without one the partials are added with float atomics as before.
 template <int T>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                        const float* __restrict__ b0, const float* __restrict__ w1,
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   __shared__ float sw[2][NP];                          // [layer][i * T + j], then the bias
   __shared__ float swT[2][T * T];                      // [layer][j * T + i]: row i of a mat-vec read by consecutive threads i
   __shared__ float lst[ATTN_LIST][4][T];
-  __shared__ int act[256];                             // pixel of the block's r-th active thread
+  __shared__ int act[256];                             // pixel of the chunk's r-th active thread
   __shared__ int wave_cnt[4];
   for (int i = threadIdx.x; i < T * T; i += blockDim.x) {
     const float a = w0[i], c = w1[i];
@@ -71,136 +75,107 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     swT[0][q * T + r] = a; swT[1][q * T + r] = c;
   }
   for (int i = threadIdx.x; i < T; i += blockDim.x) { sw[0][T * T + i] = b0[i]; sw[1][T * T + i] = b1[i]; }
-  const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  bool any = false;
-  if (p < HW) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) any |= (dout[((size_t)b * T + t) * HW + p] != 0.f);
-  }
-  // rank of this thread among the block's active pixels (wave ballots + wave offsets)
-  const unsigned long long bal = __ballot(any);
-  if (lane == 0) wave_cnt[wave] = __popcll(bal);
-  __syncthreads();                                     // also: sw / swT visible
-  int rank = __popcll(bal & ((1ull << lane) - 1ull)), nact = 0;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) { if (w < wave) rank += wave_cnt[w]; nact += wave_cnt[w]; }
-  // deterministic mode (ws.counter): every workgroup takes a ticket; ws.part = [nblk] "has a partial" flags, then [nblk][2 NP] partials
-  const unsigned nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
-  auto det_finish = [&]() {
-    if (!det_last_block(ws.counter, nblk)) return;
-    int* vlist = act;                                  // the workgroups that hold a partial, in workgroup order (LDS: act[] is free now)
-    __shared__ int nvalid;
-    if (threadIdx.x == 0) {
-      int n = 0;
-      for (unsigned b2 = 0; b2 < nblk; ++b2)
-        if (det_load(ws.part + b2) != 0.f) { if (n < 256) vlist[n] = (int)b2; ++n; }
-      nvalid = n;
-    }
-    __syncthreads();
-    const float* pp = ws.part + nblk;
-    for (int e = threadIdx.x; e < 2 * NP; e += 256) {
-      float sacc = 0.f;
-      if (nvalid <= 256) { for (int i = 0; i < nvalid; ++i) sacc += det_load(pp + (size_t)vlist[i] * 2 * NP + e); }
-      else { for (unsigned b2 = 0; b2 < nblk; ++b2) if (det_load(ws.part + b2) != 0.f) sacc += det_load(pp + (size_t)b2 * 2 * NP + e); }
-      const int l = e >= NP ? 1 : 0, q = e - l * NP;
-      float* dw = l ? dw1 : dw0;
-      float* db = l ? db1 : db0;
-      float* o = q < T * T ? dw + q : db + (q - T * T);
-      *o += sacc;
-    }
-  };
-  if (nact == 0) {                                     // block-uniform
-    if (ws.counter) {
-      if (threadIdx.x == 0) ws.part[blk] = 0.f;
-      det_finish();
-    }
-    return;
-  }
-  if (any) act[rank] = p;
-
   // element e of this thread: layer l = e / NP, index q = e % NP; q < T*T: weight (i, j) = (q / T, q % T) <- dg[i] * h[j]; else bias
   float acc[NE];
 #pragma unroll
   for (int k = 0; k < NE; ++k) acc[k] = 0.f;
-  for (int r0 = 0; r0 < nact; r0 += ATTN_LIST) {
-    const int n = min(ATTN_LIST, nact - r0);
-    __syncthreads();                                   // act visible / previous round consumed
-    int pm[PPT], pi[PPT];
-    bool ok[PPT];
-    float go[PPT], h0v[PPT], a1[PPT], dh1[PPT];
+  const int nchunk = (HW + 255) / 256;
+  for (int chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+    const int p = chunk * 256 + threadIdx.x;
+    bool any = false;
+    if (p < HW) {
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      const int pair = threadIdx.x + 256 * k;
-      pm[k] = pair / T; pi[k] = pair - pm[k] * T;
-      ok[k] = pm[k] < n;                               // (pair < ATTN_LIST * T follows: n <= ATTN_LIST)
-      if (ok[k]) {
-        const size_t o = ((size_t)b * T + pi[k]) * HW + act[r0 + pm[k]];
-        go[k] = dout[o];
-        h0v[k] = x[o];
-        lst[pm[k]][H0][pi[k]] = h0v[k];
+      for (int t = 0; t < T; ++t) any |= (dout[((size_t)b * T + t) * HW + p] != 0.f);
+    }
+    // rank of this thread among the chunk's active pixels (wave ballots + wave offsets)
+    const unsigned long long bal = __ballot(any);
+    __syncthreads();                                   // sw / swT visible (first trip); act / wave_cnt of the previous chunk consumed
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int rank = __popcll(bal & ((1ull << lane) - 1ull)), nact = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { if (w < wave) rank += wave_cnt[w]; nact += wave_cnt[w]; }
+    if (nact == 0) continue;                           // block-uniform
+    if (any) act[rank] = p;
+    for (int r0 = 0; r0 < nact; r0 += ATTN_LIST) {
+      const int n = min(ATTN_LIST, nact - r0);
+      __syncthreads();                                 // act visible / previous round consumed
+      int pm[PPT], pi[PPT];
+      bool ok[PPT];
+      float go[PPT], h0v[PPT], a1[PPT], dh1[PPT];
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int pair = threadIdx.x + 256 * k;
+        pm[k] = pair / T; pi[k] = pair - pm[k] * T;
+        ok[k] = pm[k] < n;                             // (pair < ATTN_LIST * T follows: n <= ATTN_LIST)
+        if (ok[k]) {
+          const size_t o = ((size_t)b * T + pi[k]) * HW + act[r0 + pm[k]];
+          go[k] = dout[o];
+          h0v[k] = x[o];
+          lst[pm[k]][H0][pi[k]] = h0v[k];
+        }
       }
-    }
-    __syncthreads();
+      __syncthreads();
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      if (!ok[k]) continue;
-      float g = sw[0][T * T + pi[k]];
+      for (int k = 0; k < PPT; ++k) {
+        if (!ok[k]) continue;
+        float g = sw[0][T * T + pi[k]];
 #pragma unroll 8
-      for (int j = 0; j < T; ++j) g += swT[0][j * T + pi[k]] * lst[pm[k]][H0][j];
-      a1[k] = h0v[k] + h0v[k] * g;
-      lst[pm[k]][H1][pi[k]] = a1[k] > 0.f ? a1[k] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      if (!ok[k]) continue;
-      float g = sw[1][T * T + pi[k]];
-#pragma unroll 8
-      for (int j = 0; j < T; ++j) g += swT[1][j * T + pi[k]] * lst[pm[k]][H1][j];
-      const float h1i = lst[pm[k]][H1][pi[k]];
-      const float a2 = h1i + h1i * g;
-      const float da2 = a2 > 0.f ? go[k] : 0.f;
-      lst[pm[k]][DG2][pi[k]] = da2 * h1i;
-      dh1[k] = da2 * (1.f + g);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      if (!ok[k]) continue;
-      float s = 0.f;
-#pragma unroll 8
-      for (int i = 0; i < T; ++i) s += sw[1][i * T + pi[k]] * lst[pm[k]][DG2][i];
-      const float d = dh1[k] + s;
-      const float da1 = a1[k] > 0.f ? d : 0.f;
-      lst[pm[k]][DG1][pi[k]] = da1 * h0v[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NE; ++k) {
-      const int e = threadIdx.x + 256 * k;
-      if (e >= 2 * NP) continue;
-      const int l = e >= NP ? 1 : 0, q = e - l * NP;
-      const int sd = l ? DG2 : DG1, sh = l ? H1 : H0;
-      float a = acc[k];
-      if (q < T * T) {
-        const int i = q / T, j = q % T;
-        for (int m = 0; m < n; ++m) a += lst[m][sd][i] * lst[m][sh][j];
-      } else {
-        for (int m = 0; m < n; ++m) a += lst[m][sd][q - T * T];
+        for (int j = 0; j < T; ++j) g += swT[0][j * T + pi[k]] * lst[pm[k]][H0][j];
+        a1[k] = h0v[k] + h0v[k] * g;
+        lst[pm[k]][H1][pi[k]] = a1[k] > 0.f ? a1[k] : 0.f;
       }
-      acc[k] = a;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        if (!ok[k]) continue;
+        float g = sw[1][T * T + pi[k]];
+#pragma unroll 8
+        for (int j = 0; j < T; ++j) g += swT[1][j * T + pi[k]] * lst[pm[k]][H1][j];
+        const float h1i = lst[pm[k]][H1][pi[k]];
+        const float a2 = h1i + h1i * g;
+        const float da2 = a2 > 0.f ? go[k] : 0.f;
+        lst[pm[k]][DG2][pi[k]] = da2 * h1i;
+        dh1[k] = da2 * (1.f + g);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        if (!ok[k]) continue;
+        float sm = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < T; ++i) sm += sw[1][i * T + pi[k]] * lst[pm[k]][DG2][i];
+        const float d = dh1[k] + sm;
+        const float da1 = a1[k] > 0.f ? d : 0.f;
+        lst[pm[k]][DG1][pi[k]] = da1 * h0v[k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        if (e >= 2 * NP) continue;
+        const int l = e >= NP ? 1 : 0, q = e - l * NP;
+        const int sd = l ? DG2 : DG1, sh = l ? H1 : H0;
+        float a = acc[k];
+        if (q < T * T) {
+          const int i = q / T, j = q % T;
+          for (int m = 0; m < n; ++m) a += lst[m][sd][i] * lst[m][sh][j];
+        } else {
+          for (int m = 0; m < n; ++m) a += lst[m][sd][q - T * T];
+        }
+        acc[k] = a;
+      }
     }
   }
-  if (ws.counter) {
+  if (ws.part) {                                       // ws.part = [workgroups][2 NP]: added in workgroup order by det_reduce
+    const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
       const int e = threadIdx.x + 256 * k;
-      if (e < 2 * NP) ws.part[nblk + (size_t)blk * 2 * NP + e] = acc[k];
+      if (e < 2 * NP) ws.part[(size_t)blk * 2 * NP + e] = acc[k];
     }
-    if (threadIdx.x == 0) ws.part[blk] = 1.f;
-    __syncthreads();                                   // (act[] is reused by det_finish)
-    det_finish();
     return;
   }
 #pragma unroll
@@ -293,8 +268,8 @@ __global__ void upmod_bwd_pos_kernel(const float* __restrict__ x, const float* _
   const float sch = (float)(Sh - 1) / (float)(Oh - 1), scw = (float)(Sw - 1) / (float)(Ow - 1);
   const int pix0 = blockIdx.x * blockDim.x + threadIdx.x;
   const bool pvalid = pix0 < Oh * Ow;
-  const int pix = pvalid ? pix0 : Oh * Ow - 1;         // (deterministic mode: every thread stays for the workgroup's ticket)
-  if (!pvalid && !ws.counter) return;
+  const int pix = pix0;
+  if (!pvalid) return;
   const int ox = pix % Ow, oy = pix / Ow;
   int y0, y1, x0, x1; float ly, lx;
   ac_src(oy, sch, Sh, y0, y1, ly);
@@ -309,15 +284,8 @@ __global__ void upmod_bwd_pos_kernel(const float* __restrict__ x, const float* _
   }
   const float sg = 1.f / (1.f + expf(-pos[pix]));
   const float contrib = acc * 2.f * sg * (1.f - sg);
-  if (ws.counter) {
-    // group = the gridDim.y channel-chunk workgroups of this pixel block; ws.part = [gridDim.y][gridDim.x * 256]
-    const size_t npad = (size_t)gridDim.x * blockDim.x;
-    ws.part[(size_t)blockIdx.y * npad + pix0] = contrib;
-    if (det_last_block(ws.counter + blockIdx.x, gridDim.y) && pvalid) {
-      float sacc = 0.f;
-      for (unsigned y = 0; y < gridDim.y; ++y) sacc += det_load(ws.part + (size_t)y * npad + pix0);
-      dpos[pix] += sacc;
-    }
+  if (ws.part) {                                       // ws.part = [gridDim.y chunks][pixels]: added in chunk order by det_reduce
+    if (pvalid) ws.part[(size_t)blockIdx.y * (Oh * Ow) + pix] = contrib;
     return;
   }
   atomicAdd(dpos + pix, contrib);
@@ -407,13 +375,8 @@ __global__ void dtail_bwd2_kernel(const float* __restrict__ o2, const float* __r
     acc += g * o2[i];
   }
   acc = block_sum(acc, red);
-  if (dalpha && ws.counter) {
+  if (dalpha && ws.part) {                             // ws.part = [workgroups]: added in workgroup order by det_reduce
     if (threadIdx.x == 0) ws.part[blockIdx.x] = acc * sg * (1.f - sg);
-    if (det_last_block(ws.counter, gridDim.x) && threadIdx.x == 0) {
-      float sacc = 0.f;
-      for (unsigned b2 = 0; b2 < gridDim.x; ++b2) sacc += det_load(ws.part + b2);
-      *dalpha += sacc;
-    }
     return;
   }
   if (dalpha && threadIdx.x == 0) atomicAdd(dalpha, acc * sg * (1.f - sg));
@@ -462,13 +425,8 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, const float* __re
     acc += g;
   }
   acc = block_sum(acc, red);
-  if (ws.counter) {                                    // group = the gridDim.y chunk workgroups of channel c; ws.part = [C][gridDim.y]
+  if (ws.part) {                                       // ws.part = [C][gridDim.y chunks]: added in chunk order by det_reduce
     if (threadIdx.x == 0) ws.part[(size_t)c * gridDim.y + blockIdx.y] = acc;
-    if (det_last_block(ws.counter + c, gridDim.y) && threadIdx.x == 0) {
-      float sacc = 0.f;
-      for (unsigned k = 0; k < gridDim.y; ++k) sacc += det_load(ws.part + (size_t)c * gridDim.y + k);
-      db[c] += sacc;
-    }
     return;
   }
   if (threadIdx.x == 0) atomicAdd(db + c, acc);
@@ -490,14 +448,8 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restri
     acc += (r.x + r.y) + (r.z + r.w);
   }
   acc = block_sum(acc, red);
-  if (ws.counter) {                                    // group = the gridDim.y * gridDim.z workgroups of channel c; ws.part = [C][B][chunks]
-    const unsigned per = gridDim.y * gridDim.z;
-    if (threadIdx.x == 0) ws.part[(size_t)c * per + blockIdx.y * gridDim.z + blockIdx.z] = acc;
-    if (det_last_block(ws.counter + c, per) && threadIdx.x == 0) {
-      float sacc = 0.f;
-      for (unsigned k = 0; k < per; ++k) sacc += det_load(ws.part + (size_t)c * per + k);
-      db[c] += sacc;
-    }
+  if (ws.part) {                                       // ws.part = [C][B][chunks]: added in (sample, chunk) order by det_reduce
+    if (threadIdx.x == 0) ws.part[((size_t)c * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z] = acc;
     return;
   }
   if (threadIdx.x == 0) atomicAdd(db + c, acc);
@@ -563,6 +515,32 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// second stage of the deterministic sums (common.h): thread = one output element, its partials added in ascending order
+__global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ part, int groups, int n, long long gs, long long ks, const DetSegs segs) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= groups) return;
+  const float* p = part + (long long)g * gs;
+  float sacc = 0.f;
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {                         // eight loads in flight, added in order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long long)(k + u) * ks];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sacc += v[u];
+  }
+  for (; k < n; ++k) sacc += p[(long long)k * ks];
+  int r = g;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (r < segs.len[i]) { segs.out[i][r] += sacc; return; }
+    r -= segs.len[i];
+  }
+}
+int det_reduce(const float* part, int groups, int n, long long gs, long long ks, const DetSegs& segs, hipStream_t s) {
+  P2I_LAUNCH(det_reduce_kernel, dim3(ceil_div(groups, 256)), dim3(256), 0, s, part, groups, n, gs, ks, segs);
+  return launch_status();
+}
 }  // namespace p2i
 using namespace p2i;
 
@@ -582,13 +560,22 @@ extern "C" int p2i_attn_bwd(const float* x, const float* w0, const float* b0, co
                             const float* dout, float* dw0, float* db0, float* dw1, float* db1, int B, int T, int HW, void* stream) {
   P2I_REQUIRE(x && w0 && b0 && w1 && b1 && dout && dw0 && db0 && dw1 && db1, "null pointer");
   P2I_REQUIRE(T == 8 || T == 16 || T == 32, "AttentionBlock kernels exist for T in {8, 16, 32}");
-  const dim3 grid(ceil_div(HW, 256), B);
+  // a workgroup walks several 256-pixel chunks of its sample: 64 workgroups in all (4 per CU quarter is plenty: the kernel reads
+  // dout once -- 8 MB at B = 8 -- and does real work for the few pixels with a gradient)
+  int gx = ceil_div(HW, 256);
+  const int want = 64 / (B < 64 ? B : 64) > 0 ? 64 / (B < 64 ? B : 64) : 1;
+  if (gx > want) gx = want;
+  const dim3 grid(gx, B);
   hipStream_t s = (hipStream_t)stream;
   const size_t nblk = (size_t)grid.x * grid.y;
-  const DetWs ws = det_take(nblk * (1 + 2 * (size_t)(T * T + T)), 1);
+  const DetWs ws = det_take(nblk * 2 * (size_t)(T * T + T), 1);
   if (T == 16) P2I_LAUNCH(attn_bwd_kernel<16>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW, ws);
   else if (T == 32) P2I_LAUNCH(attn_bwd_kernel<32>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW, ws);
   else P2I_LAUNCH(attn_bwd_kernel<8>, grid, dim3(256), 0, s, x, w0, b0, w1, b1, dout, dw0, db0, dw1, db1, B, HW, ws);
+  if (ws.part) {
+    const int NP = T * T + T;
+    return det_reduce(ws.part, 2 * NP, (int)nblk, 1, 2 * NP, DetSegs{{dw0, db0, dw1, db1}, {T * T, T, T * T, T}}, s);
+  }
   return launch_status();
 }
 extern "C" int p2i_pooldup_fwd(const float* x, float* y, int B, int C, int H, int W, void* stream) {
@@ -633,8 +620,11 @@ extern "C" int p2i_upmod_bwd(const float* x, const float* pos, const float* du, 
   if (dpos) {
     const int chunk = 16;
     const dim3 gp(ceil_div(4 * S * S2w, 256), ceil_div(BC, chunk));
-    const DetWs ws = det_take((size_t)gp.x * 256 * gp.y, (int)gp.x);
+    const int npix = 4 * S * S2w;
+    const DetWs ws = det_take((size_t)npix * gp.y, 0);
     P2I_LAUNCH(upmod_bwd_pos_kernel, gp, dim3(256), 0, s, x, pos, du, dpos, BC, S, S2w, chunk, ws);
+    if (ws.part)
+      if (int e = det_reduce(ws.part, npix, (int)gp.y, 1, npix, DetSegs{{dpos, nullptr, nullptr, nullptr}, {npix, 0, 0, 0}}, s)) return e;
   }
   if (dx) {
     {
@@ -661,6 +651,8 @@ extern "C" int p2i_dtail_bwd(const float* out2d, const float* alpha2d, const flo
   const int nb2 = min(ceil_div(n, 256), 64);
   const DetWs ws = dalpha2d ? det_take((size_t)nb2, 1) : DetWs{nullptr, nullptr};
   P2I_LAUNCH(dtail_bwd2_kernel, dim3(nb2), dim3(256), 0, s, out2d, alpha2d, dfused, dout2d, dalpha2d, n, ws);
+  if (ws.part)
+    if (int e = det_reduce(ws.part, 1, nb2, 0, 1, DetSegs{{dalpha2d, nullptr, nullptr, nullptr}, {1, 0, 0, 0}}, s)) return e;
   if (dout3d)
     P2I_LAUNCH(dtail_bwd3_kernel, dim3(ceil_div(B * H3 * W3, 256)), dim3(256), 0, s, dfused, dout3d, B, H2, W2, T3, H3, W3);
   return launch_status();
@@ -671,8 +663,9 @@ extern "C" int p2i_bias_grad(const float* dy, const float* y_act, int act, float
   int chunks = (int)((total + 16383) / 16384);
   if (chunks > 64) chunks = 64;
   if (chunks < 1) chunks = 1;
-  const DetWs ws = det_take((size_t)C * chunks, C);
+  const DetWs ws = det_take((size_t)C * chunks, 0);
   P2I_LAUNCH(bias_grad_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dy, y_act, act, db, B, C, inner, ws);
+  if (ws.part) return det_reduce(ws.part, C, chunks, chunks, 1, DetSegs{{db, nullptr, nullptr, nullptr}, {C, 0, 0, 0}}, (hipStream_t)stream);
   return launch_status();
 }
 extern "C" int p2i_act_bwd(const float* dy, const float* y, int act, float* out, int64_t n, void* stream) {
@@ -685,8 +678,9 @@ extern "C" int p2i_act_bwd_bias(const float* dy, const float* y, int act, float*
   P2I_REQUIRE((inner & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) & 15) == 0, "inner % 4 and 16-byte alignment");
   int chunks = (int)((inner / 4 + 2047) / 2048);
   if (chunks > 16) chunks = 16;
-  const DetWs ws = det_take((size_t)C * B * chunks, C);
+  const DetWs ws = det_take((size_t)C * B * chunks, 0);
   P2I_LAUNCH(act_bwd_bias_kernel, dim3(C, B, chunks), dim3(256), 0, (hipStream_t)stream, dy, y, act, out, db, C, inner / 4, ws);
+  if (ws.part) return det_reduce(ws.part, C, B * chunks, B * chunks, 1, DetSegs{{db, nullptr, nullptr, nullptr}, {C, 0, 0, 0}}, (hipStream_t)stream);
   return launch_status();
 }
 extern "C" int p2i_axpy(float* y, const float* x, float a, int64_t n, void* stream) {

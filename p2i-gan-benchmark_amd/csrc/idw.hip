@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void idw_bwd_kernel(const float* __restrict__ 
 // (idw_absmax_kernel: an integer max over the float bit patterns, order-free too) so that the sum of all 4 Q contributions of a
 // sample stays below 2^61: a contribution g * w (rounded to float as before) times 2^k is converted exactly unless it is smaller than
 // 2^-41 of the largest -- more accurate than the float atomics it replaces.  ctl[0] = bits of max |dout|, ctl[1] = ticket of the
-// last kernel (both zero between calls).
+// last kernel.
 __global__ __launch_bounds__(256) void idw_absmax_kernel(const float* __restrict__ dout, size_t n, unsigned* ctl) {
   __shared__ float red[16];
   float m = 0.f;
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void idw_bwd_fix_kernel(const float* __restric
     }
   }
 }
-// d vals[pt_pos[j]] = fixed-point sum / scale; the last workgroup clears the control words for the next call
+// d vals[pt_pos[j]] = fixed-point sum / scale
 __global__ __launch_bounds__(256) void idw_bwd_fix_finish_kernel(const unsigned long long* __restrict__ acc64, const int32_t* __restrict__ pt_pos,
                                                                 const int32_t* __restrict__ pt_count, float* dvals, unsigned* ctl, int Q) {
   const int b = blockIdx.y;
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void idw_bwd_fix_finish_kernel(const unsigned 
       dvals[(size_t)b * Q + pp[j]] = (float)ldexp((double)v, -k);
     }
   }
-  if (det_last_block(ctl + 1, gridDim.x * gridDim.y) && threadIdx.x == 0) ctl[0] = 0u;
+  (void)ctl;
 }
 
 }  // namespace p2i
@@ -814,19 +814,20 @@ extern "C" int p2i_idw_bwd(const float* dout, const int32_t* pt_pos, const int32
   const int chunk = 4096;
   hipStream_t s = (hipStream_t)stream;
   // deterministic mode: 8 bytes of fixed-point accumulator per voxel slot (a sample has at most Q points) from the registered scratch
-  const DetWs ws = det_take(2 * total + 64, 2);
-  if (ws.counter != nullptr && (reinterpret_cast<uintptr_t>(ws.part) & 7) == 0) {
+  const DetWs ws = det_take(2 * total + 64, 0);
+  if (ws.part != nullptr && (reinterpret_cast<uintptr_t>(ws.part) & 7) == 0) {
     unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(ws.part);
-    (void)p2i::memset_async(acc64, 0, sizeof(unsigned long long) * total, s);
+    unsigned* ctl = reinterpret_cast<unsigned*>(ws.part + 2 * total);            // the max |dout| bits, behind the accumulators
+    (void)p2i::memset_async(acc64, 0, sizeof(unsigned long long) * total + 64, s);
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)idw_bwd_fix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       attr_set = true;
     }
-    P2I_LAUNCH(idw_absmax_kernel, dim3(256), dim3(256), 0, s, dout, total, ws.counter);
+    P2I_LAUNCH(idw_absmax_kernel, dim3(256), dim3(256), 0, s, dout, total, ctl);
     P2I_LAUNCH(idw_bwd_fix_kernel, dim3(ceil_div(Q, chunk), B), dim3(256), sizeof(unsigned long long) * IDW_LDS_PTS, s, dout, pt_count, sel_idx,
-               sel_w, acc64, ws.counter, Q, chunk);
-    P2I_LAUNCH(idw_bwd_fix_finish_kernel, dim3(16, B), dim3(256), 0, s, acc64, pt_pos, pt_count, dvals_src, ws.counter, Q);
+               sel_w, acc64, ctl, Q, chunk);
+    P2I_LAUNCH(idw_bwd_fix_finish_kernel, dim3(16, B), dim3(256), 0, s, acc64, pt_pos, pt_count, dvals_src, ctl, Q);
     return launch_status();
   }
   P2I_LAUNCH(idw_bwd_kernel, dim3(ceil_div(Q, chunk), B), dim3(256), 0, s, dout, pt_pos, pt_count, sel_idx, sel_w, dvals_src, Q, chunk);

@@ -100,7 +100,7 @@ static int event_op(int kind, int slot, hipStream_t s, bool record_it) {
   return P2I_OK;
 }
 
-// ---- scratch of the deterministic reductions (common.h: det_last_block).  Registered once by the caller (caller-owned device
+// ---- scratch of the deterministic reductions (common.h: det_take / det_reduce).  Registered once by the caller (caller-owned device
 // memory); every call that needs scratch takes the next piece of the ring.  Pieces are reused only after the ring has wrapped:
 // with the ring sized for many calls (the Python binding registers 64 MB for ~5 MB per train step) the kernels that used a piece
 // before have long finished -- the steps of a training run are chained through the weights.

@@ -359,13 +359,8 @@ __global__ void unpack_dot_kernel(const float* __restrict__ dwp, const float* __
     acc += dwp[((size_t)tap * I + i) * pad32(O) + o] * w[idx];
   }
   acc = block_sum(acc, red);
-  if (ws.counter) {
+  if (ws.part) {
     if (threadIdx.x == 0) ws.part[blockIdx.x] = acc;
-    if (det_last_block(ws.counter, gridDim.x) && threadIdx.x == 0) {
-      float sacc = 0.f;
-      for (unsigned k = 0; k < gridDim.x; ++k) sacc += det_load(ws.part + k);
-      *dot = sacc;
-    }
     return;
   }
   if (threadIdx.x == 0) atomicAdd(dot, acc);
@@ -564,7 +559,10 @@ extern "C" int p2i_weight_unpack_grad(const float* dwp_f, int O, int I, int ntap
   if (sigma_ptr) {
     (void)p2i::memset_async(scratch, 0, sizeof(float), s);
     const int nbd = min(ceil_div(n, 256), 256);
-    P2I_LAUNCH(unpack_dot_kernel, dim3(nbd), dim3(256), 0, s, dwp_f, w_orig, O, I, ntaps, scratch, det_take((size_t)nbd, 1));
+    const DetWs ws = det_take((size_t)nbd, 0);
+    P2I_LAUNCH(unpack_dot_kernel, dim3(nbd), dim3(256), 0, s, dwp_f, w_orig, O, I, ntaps, scratch, ws);
+    if (ws.part)
+      if (int e = det_reduce(ws.part, 1, nbd, 0, 1, DetSegs{{scratch, nullptr, nullptr, nullptr}, {1, 0, 0, 0}}, s)) return e;
   }
   P2I_LAUNCH(unpack_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dwp_f, O, I, ntaps, sigma_ptr, scratch, u, v, dw);
   return launch_status();
@@ -683,13 +681,8 @@ __global__ void unpack_dot_batched_kernel(const PackBatch b, DetWs ws) {
     acc += b.g[L][((size_t)tap * I + i) * pad32(O) + o] * b.w[L][idx];
   }
   acc = block_sum(acc, red);
-  if (ws.counter) {                                    // group = the gridDim.x workgroups of layer L; ws.part = [layers][gridDim.x]
+  if (ws.part) {                                       // ws.part = [layers][gridDim.x]: added in workgroup order by det_reduce
     if (threadIdx.x == 0) ws.part[(size_t)L * gridDim.x + blockIdx.x] = acc;
-    if (det_last_block(ws.counter + L, gridDim.x) && threadIdx.x == 0) {
-      float sacc = 0.f;
-      for (unsigned k = 0; k < gridDim.x; ++k) sacc += det_load(ws.part + (size_t)L * gridDim.x + k);
-      *b.dot[L] = sacc;
-    }
     return;
   }
   if (threadIdx.x == 0 && acc != 0.f) atomicAdd(b.dot[L], acc);
@@ -748,8 +741,11 @@ extern "C" int p2i_weight_unpack_grad_batched_acc(const float* const* dwp_f, con
   if (any_sigma) {
     (void)p2i::memset_async(dots, 0, sizeof(float) * n, s);
     const int nbd = blocks > 128 ? 128 : blocks;
-    const DetWs ws = det_take((size_t)nbd * n, n);
+    const DetWs ws = det_take((size_t)nbd * n, 0);
+    if (ws.part) (void)p2i::memset_async(ws.part, 0, sizeof(float) * (size_t)nbd * n, s);     // (layers without sigma store nothing)
     P2I_LAUNCH(unpack_dot_batched_kernel, dim3(nbd, 1, n), dim3(256), 0, s, b, ws);
+    if (ws.part)
+      if (int e = det_reduce(ws.part, n, nbd, nbd, 1, DetSegs{{dots, nullptr, nullptr, nullptr}, {n, 0, 0, 0}}, s)) return e;
   }
   P2I_LAUNCH(unpack_batched_kernel, dim3(blocks > 512 ? 512 : blocks, 1, n), dim3(256), 0, s, b);
   return launch_status();
