@@ -342,6 +342,15 @@ int p2i_act_bwd_bias(const float* dy, const float* y, int act, float* out, float
  *     of events without timing) to be seen by a tape; enqueue-only like everything else, no synchronisation;
  *   - host-side values baked into kernel arguments are replayed as recorded (use p2i_adam_dev, whose step counter lives on the
  *     device). */
+/* ---- Pre-split source planes (round 4, EXPERIMENT: measured, not used by the engine -- DESIGN.md section 7).  p2i_x6_split_planes:
+ * fp32 activations (B, C, P) (P = frames x pixels, C % 8 == 0) -> their exact 3-way bf16 split as planes [plane][b][C/8][P][8]
+ * (3 * B * C * P bf16, caller-owned).  p2i_x6_next_source_planes: the next split-pipe forward / data-gradient call of the calling
+ * thread (p2i_conv_fwd_x6s / _dgrad_x6s ...) reads its source from these planes instead of splitting the fp32 tensor in the kernel
+ * (32-channel tiles with whole-chunk stages; any other tile ignores them); the same deconv_pytorch.py:103-109 convolution, bit-equal
+ * results (tests/test_ops_gpu.py::test_presplit_source_planes_are_bit_equal). */
+int p2i_x6_split_planes(const float* x, void* planes, int B, int C, int64_t P, void* stream);
+int p2i_x6_next_source_planes(const void* planes);
+
 /* ---- Run-to-run reproducibility (round 4).  The step's small cross-workgroup sums (bias / position / attention-weight / alpha
  * gradients, spectral-norm dot products, the 1 -> 32 layer's weight gradient, the IDW backward scatter) are float atomics by
  * default: their order, hence their rounding, changes from run to run (the reference on CPU is deterministic).  With a scratch

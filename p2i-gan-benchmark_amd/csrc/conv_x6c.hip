@@ -91,6 +91,24 @@ __global__ __launch_bounds__(256) void wsplit_batched_kernel(const WsplitBatch b
   }
 }
 
+// fp32 activations (B, C, P) (P = frames x pixels, C % 8 == 0) -> bf16 planes [plane][b][k/8][P][8]: the exact 3-way split of
+// split8c, made ONCE per tensor instead of once per (channel tile, position tile) of every kernel that consumes it
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, u32x4c* __restrict__ planes, int B, int KCt, long long P) {
+  const long long total = (long long)B * KCt * P;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long pix = i % P, r = i / P;          // r = b * KCt + kg
+    const float* px = x + (r * 8) * P + pix;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = px[(long long)q * P];
+    u32x4c h, mi, lo;
+    split8c(v, h, mi, lo);
+    planes[i] = h;
+    planes[total + i] = mi;
+    planes[2 * total + i] = lo;
+  }
+}
+
 X6Ctx& x6_ctx() {
   static thread_local X6Ctx c{nullptr, 0};
   return c;
@@ -122,6 +140,10 @@ struct X6cGeom {
   int fused_atomic;     // FUSED kernels with split-K: the class pairs are ADDED to a zeroed destination
   int stagger;          // waves 4-7 (the SIMD partners of waves 0-3) run a stage's staging work AFTER its first taps instead of before
   int vec4_epi;         // epilogue through LDS with 16-byte global accesses (epilogue_tile16_v4): host-checked alignment / extents
+  // PRE kernels (round 4 experiment): the source as pre-split bf16 planes [plane][b][k/8][frame, pixel][8] (split_planes_kernel):
+  // 16-byte units; plane p starts plane_units units behind plane p - 1
+  const u32x4c* splanes;
+  unsigned plane_units;
 };
 
 // FUSED (data gradient of a stride-(.,2,2) 3x3 convolution: conv_fused.hip on the bf16 matrix pipe): the nine taps of a chunk belong
@@ -759,7 +781,7 @@ __global__ __launch_bounds__(64 * NW) void patch_gemm_x6c_kernel(const X6cGeom g
 // TN = position blocks of 32 per consumer wave: 2 (256 positions per workgroup) or 1 (128: layers with so few positions that 32 x 256
 // tiles would need split-K -- the 512-channel level at B = 8 -- get twice the workgroups instead of a zero-filled destination, atomic
 // partial sums and a second activation pass; no epilogue exchange then: a consumer has one accumulator tile)
-template <int TM, int TPS, bool FUSED = false, bool EPI4 = false, int NPW = 4, int TN = 2>
+template <int TM, int TPS, bool FUSED = false, bool EPI4 = false, int NPW = 4, int TN = 2, bool PRE = false>
 __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6cGeom g) {
   constexpr int NSTG = 9 / TPS;
   constexpr int NCLS = FUSED ? 4 : 1;                     // FUSED: see X6C_CLS (strided data gradient, four parity classes)
@@ -802,7 +824,8 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
     const int eh = row - jb * g.eH;
     const int n = j0b + jb, h = src_h0 + eh, w = src_w0 + ew;
     const int b = n / g.nT, lt = n - b * g.nT;
-    ptab[e] = (n < nimg && (unsigned)h < (unsigned)g.sH && (unsigned)w < (unsigned)g.sW) ? ((b * g.Ck) * g.sT + lt * g.mT) * sHW + h * g.sW + w : -1;
+    // (PRE: offsets count 16-byte units of a plane -- 8 channels of one pixel -- instead of floats)
+    ptab[e] = (n < nimg && (unsigned)h < (unsigned)g.sH && (unsigned)w < (unsigned)g.sW) ? ((b * (PRE ? KCt : g.Ck)) * g.sT + lt * g.mT) * sHW + h * g.sW + w : -1;
   }
   __syncthreads();                                                        // ptab visible
 
@@ -824,14 +847,38 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
       const int kg = item >= CSl ? 1 : 0, e = item - kg * CSl;
       const bool in = item < 2 * CSl;
       const int po = in ? ptab[e] : -1;
-      it_off[it] = po < 0 ? -1 : po + kg * 8 * cs;
+      it_off[it] = po < 0 ? -1 : po + kg * (PRE ? 1 : 8) * cs;
       it_dst[it] = in ? kg * CSl + e : -1;
       const int jbi = fast_div(fast_div(in ? e : 0, g.mg_ew), g.mg_eh);
       it_f0[it] = ((j0b + jbi) % g.nT) * g.mT;
     }
-    float pv[NI][8];
+    float pv[PRE ? 1 : NI][8];
+    u32x4c pq[PRE ? NI : 1][3];                                          // PRE: the item's three planes as they come from memory
     bool pok[NI];
     auto load_patch = [&](int c) {
+      if constexpr (PRE) {
+        const int cg = c0 + c;
+        const int j = cg >= 2 * cps ? 2 : (cg >= cps ? 1 : 0);
+        const int dt = j == 2 ? g.sdt2 : (j == 1 ? g.sdt1 : g.sdt0);
+        int voff[NI];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+          pok[it] = it_off[it] >= 0 && (unsigned)(it_f0[it] + dt) < (unsigned)g.sT;
+          voff[it] = pok[it] ? (it_off[it] + dt * sHW) * 16 : 0;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const u32x4c* sq = g.splanes + (size_t)p * g.plane_units + (size_t)(cg - j * cps) * 2 * cs;
+          const unsigned long long sq_u = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)sq) & 0xffffffffull;
+          const unsigned long long sq_hi = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)sq >> 32));
+          const unsigned long long sbase = sq_u | (sq_hi << 32);
+#pragma unroll
+          for (int it = 0; it < NI; ++it) {
+            if (it == 0) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(pq[it][p]) : "v"(voff[it]), "s"(sbase) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pq[it][p]) : "v"(voff[it]), "s"(sbase) : "memory");
+          }
+        }
+      } else {
       const int cg = c0 + c;
       const int j = cg >= 2 * cps ? 2 : (cg >= cps ? 1 : 0);
       const int dt = j == 2 ? g.sdt2 : (j == 1 ? g.sdt1 : g.sdt0);
@@ -854,8 +901,23 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
           else asm volatile("global_load_dword %0, %1, %2" : "=v"(pv[it][q]) : "v"(voff[it]), "s"(sbase) : "memory");
         }
       }
+      }
     };
     auto split_patch = [&](u32x4c* pb) {
+      if constexpr (PRE) {                                                // nothing to split: three 16-byte LDS writes per item
+#pragma unroll
+        for (int it = 0; it < NI; ++it)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(pq[it][p]));    // values exist from here on
+        const u32x4c zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+          if (it_dst[it] < 0) continue;
+          pb[it_dst[it]] = pok[it] ? pq[it][0] : zero;
+          pb[2 * CSl + it_dst[it]] = pok[it] ? pq[it][1] : zero;
+          pb[4 * CSl + it_dst[it]] = pok[it] ? pq[it][2] : zero;
+        }
+      } else {
 #pragma unroll
       for (int it = 0; it < NI; ++it)
 #pragma unroll
@@ -871,6 +933,7 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
         pb[it_dst[it]] = h;
         pb[2 * CSl + it_dst[it]] = mi;
         pb[4 * CSl + it_dst[it]] = lo;
+      }
       }
     };
     constexpr int NWR = (NWI + NPW - 1) / NPW;
@@ -897,7 +960,7 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
         if (pw + NPW * r < NWI) dma_b128(rs_w, w_dst[r] + 16u * (unsigned)(sb * WST), wvoff, w_soff[r][b] + soff);
     };
     const int nw_mine = (NWI / NPW) + (pw < NWI % NPW ? 1 : 0);
-    constexpr int NPL = 8 * NI;
+    constexpr int NPL = (PRE ? 3 : 8) * NI;                                 // patch loads per thread and chunk
     // (the weights of the first LEAD stages are DMA'd by the CONSUMER waves, which have nothing else to do during the prologue)
     auto nwb = [&](int st) { return (st >= LEAD && st < nst) ? nw_mine : 0; };
     // vector-memory operations of a producer wave, in issue order: prologue [P(0)]; per stage s:
@@ -1293,15 +1356,17 @@ static void x6c_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
   }
   P2I_LAUNCH((patch_gemm_x6c_kernel<NW, TM, FUSED, TPS>), grid, dim3(64 * NW), lds, s, g);
 }
-template <int TM, int TPS, bool FUSED = false, bool EPI4 = false, int NPW = 4, int TN = 2>
+template <int TM, int TPS, bool FUSED = false, bool EPI4 = false, int NPW = 4, int TN = 2, bool PRE = false>
 static void x6p_launch(const X6cGeom& g, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW, TN, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  P2I_LAUNCH((patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW, TN>), grid, dim3(64 * (4 + NPW)), lds, s, g);
+  P2I_LAUNCH((patch_gemm_x6p_kernel<TM, TPS, FUSED, EPI4, NPW, TN, PRE>), grid, dim3(64 * (4 + NPW)), lds, s, g);
 }
+// experiment (round 4): the source planes of the NEXT split-pipe launch of this thread (tools/presplit_probe.py); consumed by it
+static thread_local const void* g_next_splanes = nullptr;
 // P2I_X6P_NPW=4: one producer wave per SIMD for the 32-channel tiles too (default 8); read per call (A/B runs)
 static int x6p_npw() { const char* e = getenv("P2I_X6P_NPW"); return (e && atoi(e) == 4) ? 4 : 8; }
 // Producer / consumer wave roles (patch_gemm_x6p_kernel): the default for every layer with more than one 16-channel chunk;
@@ -1394,6 +1459,15 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   for (int i = 0; i < 9; ++i) { k.tap_off[i] = g.tap_off[i]; k.tap_w[i] = g.tap_w[i]; }
   k.sT = g.sT; k.nT = g.nT; k.mT = g.mT; k.oT = g.oT; k.pT = g.pT; k.ns = ns;
   k.stagger = x6c_stagger();
+  const int pc = x6c_pc();
+  k.splanes = nullptr; k.plane_units = 0;
+  if (g_next_splanes != nullptr) {                        // pre-split source (32-channel tiles with whole-chunk stages only)
+    if (pc && g.Ck >= 32 && tv.TM == 1 && tps == 9 && pk.ksplit == 1) {
+      k.splanes = static_cast<const u32x4c*>(g_next_splanes);
+      k.plane_units = (unsigned)((long long)g.B * (g.Ck >> 3) * g.sT * g.sH * g.sW);
+    }
+    g_next_splanes = nullptr;
+  }
   {
     static const int v4_on = getenv("P2I_X6C_EPI4") ? atoi(getenv("P2I_X6C_EPI4")) : 1;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
@@ -1405,11 +1479,14 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   k.sdt0 = cs.dt[0]; k.swt0 = 0;
   k.sdt1 = ns > 1 ? cs.dt[9] : 0; k.swt1 = ns > 1 ? cs.tw[9] - cs.tw[0] : 0;
   k.sdt2 = ns > 2 ? cs.dt[18] : 0; k.swt2 = ns > 2 ? cs.tw[18] - cs.tw[0] : 0;
-  const int pc = x6c_pc();
   if (pc && g.Ck >= 32) {                                 // (a single 16-channel chunk is all prologue and epilogue: symmetric kernel)
     if (tv.TM == 2) { if (k.vec4_epi) x6p_launch<2, 3, false, true>(k, grid, lds, s); else x6p_launch<2, 3>(k, grid, lds, s); }
-    else if (tv.NW == 4) x6p_launch<1, 9, false, false, 8, 1>(k, grid, lds, s);
-    else if (tps == 9) { if (x6p_npw() == 8) x6p_launch<1, 9, false, false, 8>(k, grid, lds, s); else x6p_launch<1, 9>(k, grid, lds, s); }
+    else if (tv.NW == 4) { if (k.splanes) x6p_launch<1, 9, false, false, 8, 1, true>(k, grid, lds, s); else x6p_launch<1, 9, false, false, 8, 1>(k, grid, lds, s); }
+    else if (tps == 9) {
+      if (k.splanes && x6p_npw() == 8) x6p_launch<1, 9, false, false, 8, 2, true>(k, grid, lds, s);
+      else if (x6p_npw() == 8) x6p_launch<1, 9, false, false, 8>(k, grid, lds, s);
+      else x6p_launch<1, 9>(k, grid, lds, s);
+    }
     else x6p_launch<1, 3>(k, grid, lds, s);
   } else if (tv.TM == 2) x6c_launch<8, 2>(k, grid, lds, s);
   else if (tps == 9) x6c_launch<8, 1, false, 9>(k, grid, lds, s);
@@ -1523,4 +1600,20 @@ extern "C" int p2i_x6_split_batched(const float* const* wp, uint16_t* const* wb,
   const int blocks = (maxn + 255) / 256;
   P2I_LAUNCH(wsplit_batched_kernel, dim3(blocks > 1024 ? 1024 : blocks, n), dim3(256), 0, (hipStream_t)stream, b);
   return launch_status();
+}
+
+// ---- pre-split source planes (round 4 experiment; tools/presplit_probe.py).  p2i_x6_split_planes: fp32 (B, C, frames x pixels) ->
+// planes; p2i_x6_next_source_planes: the next split-pipe forward / data-gradient call of this thread reads its source from them
+// (32-channel tiles with whole-chunk stages; any other tile ignores them).
+extern "C" int p2i_x6_split_planes(const float* x, void* planes, int B, int C, int64_t P, void* stream) {
+  P2I_REQUIRE(x && planes && B > 0 && C > 0 && (C & 7) == 0 && P > 0, "split planes: C % 8 == 0");
+  const long long total = (long long)B * (C >> 3) * P;
+  const long long blocks = (total + 255) / 256;
+  P2I_LAUNCH(p2i::split_planes_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, (hipStream_t)stream, x,
+             static_cast<p2i::u32x4c*>(planes), B, C >> 3, (long long)P);
+  return p2i::launch_status();
+}
+extern "C" int p2i_x6_next_source_planes(const void* planes) {
+  p2i::g_next_splanes = planes;
+  return P2I_OK;
 }

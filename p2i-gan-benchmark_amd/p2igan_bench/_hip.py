@@ -80,6 +80,8 @@ SIGNATURES = {
     "p2i_bias_grad": [_P, _P, _I, _P, _I, _I, _L, _P],
     "p2i_act_bwd_bias": [_P, _P, _I, _P, _P, _I, _I, _L, _P],
     "p2i_det_workspace": [_P, _L, _P, _I],
+    "p2i_x6_split_planes": [_P, _P, _I, _I, _L, _P],
+    "p2i_x6_next_source_planes": [_P],
     "p2i_event_record": [_I, _P],
     "p2i_event_wait": [_I, _P],
     "p2i_tape_begin": [_P],

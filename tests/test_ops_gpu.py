@@ -846,3 +846,30 @@ def test_wgrad_x6_producer_consumer_variant_matches_symmetric_kernel(ops, monkey
         assert rel_err(res[1][0].cpu().numpy(), res[0][0].cpu().numpy()) < 2e-6
         if bias:
             assert rel_err(res[1][1].cpu().numpy(), res[0][1].cpu().numpy()) < 1e-5      # (bias sums are atomic adds in both)
+
+
+@pytest.mark.parametrize("C,S", [(256, 32), (512, 16)], ids=["L2_256@32", "L3_512@16"])
+def test_presplit_source_planes_are_bit_equal(ops, monkeypatch, C, S):
+    """Round-4 experiment (p2i_x6_split_planes / p2i_x6_next_source_planes): a split-pipe convolution that reads its source as
+    pre-split bf16 planes runs the same three planes through the same MFMAs as the in-kernel split: forward and data gradient are
+    bit-equal on the 32-channel tiles it applies to (32 x 256 at 256 channels, 32 x 128 at 512)."""
+    B = 8
+    lib = ops._hip.load()
+    spec = ops.ConvSpec(C, C, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    x = _rand(B, C, S, S, seed=1).cuda()
+    wp_f, wp_d = ops.weight_pack((_rand(C, C, 9, seed=2) * 0.05).cuda())
+    ops.x6_presplit([wp_f, wp_d], [True, True])
+    planes = torch.empty(3 * x.numel(), device="cuda", dtype=torch.int16)
+    ops._hip.check(lib.p2i_x6_split_planes(x.data_ptr(), planes.data_ptr(), B, C, S * S, torch.cuda.current_stream().cuda_stream), "split")
+    res = _rand(B, C, S, S, seed=3).cuda()
+    y0 = ops.conv_fwd(spec, x, wp_f, residual=res, act=ops.ACT_RELU)
+    assert _last_plan(ops)[5] == 7 and _last_plan(ops)[0] == 32, _last_plan(ops)
+    lib.p2i_x6_next_source_planes(planes.data_ptr())
+    y1 = ops.conv_fwd(spec, x, wp_f, residual=res, act=ops.ACT_RELU)
+    assert torch.equal(y0, y1)
+    d0 = ops.conv_dgrad(spec, x, wp_d, tuple(x.shape), add=res, mask_y=res, mask_act=ops.ACT_RELU)
+    lib.p2i_x6_next_source_planes(planes.data_ptr())
+    d1 = ops.conv_dgrad(spec, x, wp_d, tuple(x.shape), add=res, mask_y=res, mask_act=ops.ACT_RELU)
+    assert torch.equal(d0, d1)
+    y2 = ops.conv_fwd(spec, x, wp_f, residual=res, act=ops.ACT_RELU)          # the planes were consumed: back to the in-kernel split
+    assert torch.equal(y0, y2)
