@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void c1_dgrad_kernel(const p2i_conv_desc d, co
 // row segment pair), thread = (o = tid & 31, tap slot = tid >> 5), register accumulators, one atomic per (tap,o)
 template <int NPW>      // output pixels per tile row (32)
 __global__ __launch_bounds__(256) void c1_wgrad_kernel(const p2i_conv_desc d, const float* __restrict__ x, const float* __restrict__ dy,
-                                                      float* dwp, float* dbias, int ntiles_w, int ntiles) {
+                                                      float* dwp, float* dbias, int ntiles_w, int ntiles, DetWs ws) {
   extern __shared__ float sm[];
   const int eW = (NPW - 1) * d.sw + d.kw, eH = d.sh + d.kh;          // 2 output rows per tile
   float* sx = sm;                                    // [kt][eH][eW]
@@ -100,6 +100,13 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const p2i_conv_desc d, co
       }
     }
   }
+  if (ws.part) {                                       // ws.part = [workgroups][33 rows x 32]: rows = taps (<= 32), then the bias row
+    float* pp = ws.part + (size_t)blockIdx.x * (33 * 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pp[(slot + 8 * j) * 32 + o] = (toff[j] >= 0 && o < d.Cout) ? acc[j] : 0.f;
+    if (slot == 0) pp[32 * 32 + o] = o < d.Cout ? bsum : 0.f;
+    return;
+  }
   if (o < d.Cout) {
     const int CoPad = (d.Cout + 31) / 32 * 32;
 #pragma unroll
@@ -139,7 +146,15 @@ int c1_wgrad(const p2i_conv_desc* d, const float* x, const float* dy, float* dwp
   const int eW = (NPW - 1) * d->sw + d->kw, eH = d->sh + d->kh;
   const size_t lds = sizeof(float) * ((size_t)d->kt * eH * eW + (size_t)d->Cout * (2 * NPW + 1));
   const int grid = ntiles < 1024 ? ntiles : 1024;
-  P2I_LAUNCH(c1_wgrad_kernel<NPW>, dim3(grid), dim3(256), lds, s, *d, x, dy, dwp, dbias, ntw, ntiles);
+  const int ntaps = d->kt * d->kh * d->kw;
+  // (Cout <= 32: CoPad == 32, the packed gradient is [tap][32]; deterministic mode: partials per workgroup, summed by det_reduce)
+  const DetWs ws = (ntaps <= 32 && d->Cout <= 32) ? det_take((size_t)grid * 33 * 32, 0) : DetWs{nullptr, nullptr};
+  P2I_LAUNCH(c1_wgrad_kernel<NPW>, dim3(grid), dim3(256), lds, s, *d, x, dy, dwp, dbias, ntw, ntiles, ws);
+  if (ws.part) {
+    if (int e = det_reduce(ws.part, ntaps * 32, grid, 1, 33 * 32, DetSegs{{dwp, nullptr, nullptr, nullptr}, {ntaps * 32, 0, 0, 0}}, s)) return e;
+    if (dbias) return det_reduce(ws.part + 32 * 32, d->Cout, grid, 1, 33 * 32, DetSegs{{dbias, nullptr, nullptr, nullptr}, {d->Cout, 0, 0, 0}}, s);
+    return P2I_OK;
+  }
   return launch_status();
 }
 

@@ -22,7 +22,7 @@ __device__ __forceinline__ float rain_rate(float x, int apply) { return apply ? 
 
 __global__ __launch_bounds__(256) void metrics_pointwise_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                                 long long n, MetricArgs a, float* __restrict__ sums,
-                                                                unsigned long long* __restrict__ counts, uint8_t* __restrict__ bits) {
+                                                                unsigned long long* __restrict__ counts, uint8_t* __restrict__ bits, DetWs ws) {
   __shared__ float red[16];
   float s_abs = 0.f, s_sq = 0.f;
   unsigned c[MAX_THR][4];
@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256) void metrics_pointwise_kernel(const float* __r
   s_abs = block_sum(s_abs, red);
   s_sq = block_sum(s_sq, red);
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[0], s_abs);
-    atomicAdd(&sums[1], s_sq);
+    if (ws.part) { ws.part[2 * blockIdx.x] = s_abs; ws.part[2 * blockIdx.x + 1] = s_sq; }     // added in workgroup order by det_reduce
+    else { atomicAdd(&sums[0], s_abs); atomicAdd(&sums[1], s_sq); }
   }
 #pragma unroll
   for (int k = 0; k < MAX_THR; ++k)
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void metrics_pointwise_kernel(const float* __r
 
 // one thread per output position (i, j) of the (H+1) x (W+1) frame; scales whose output is H x W mask the last row/col
 __global__ __launch_bounds__(256) void metrics_fss_kernel(const uint8_t* __restrict__ bits, int N, int H, int W, MetricArgs a,
-                                                          float* __restrict__ num, float* __restrict__ den) {
+                                                          float* __restrict__ num, float* __restrict__ den, DetWs ws) {
   __shared__ float red[16];
   const int Ho = H + 1, Wo = W + 1;
   const long long total = (long long)N * Ho * Wo;
@@ -116,8 +116,13 @@ __global__ __launch_bounds__(256) void metrics_fss_kernel(const uint8_t* __restr
       if (k < a.nt && si < a.ns) {
         const float vn = block_sum(ln[k][si], red), vd = block_sum(ld[k][si], red);
         if (threadIdx.x == 0) {
-          atomicAdd(&num[k * a.ns + si], vn);
-          atomicAdd(&den[k * a.ns + si], vd);
+          if (ws.part) {       // [workgroups][2][nt * ns]: added in workgroup order by det_reduce
+            ws.part[((size_t)blockIdx.x * 2 + 0) * (a.nt * a.ns) + k * a.ns + si] = vn;
+            ws.part[((size_t)blockIdx.x * 2 + 1) * (a.nt * a.ns) + k * a.ns + si] = vd;
+          } else {
+            atomicAdd(&num[k * a.ns + si], vn);
+            atomicAdd(&den[k * a.ns + si], vd);
+          }
         }
       }
 }
@@ -143,8 +148,10 @@ extern "C" int p2i_metrics_pointwise(const float* pred, const float* target, int
   MetricArgs a;
   if (int e = fill_args(a, thresholds_host, nt, nullptr, 0, apply_transform)) return e;
   const long long blocks = (n + 256 * 8 - 1) / (256 * 8);
-  P2I_LAUNCH(metrics_pointwise_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream,
-                     pred, target, (long long)n, a, sums2, counts, bits);
+  const int nb = (int)(blocks > 4096 ? 4096 : blocks);
+  const DetWs ws = det_take((size_t)2 * nb, 0);
+  P2I_LAUNCH(metrics_pointwise_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, pred, target, (long long)n, a, sums2, counts, bits, ws);
+  if (ws.part) return det_reduce(ws.part, 2, nb, 1, 2, DetSegs{{sums2, nullptr, nullptr, nullptr}, {2, 0, 0, 0}}, (hipStream_t)stream);
   return launch_status();
 }
 
@@ -156,7 +163,10 @@ extern "C" int p2i_metrics_fss(const uint8_t* bits, int N, int H, int W, int nt,
   if (int e = fill_args(a, dummy, nt, scales_host, ns, 1)) return e;
   const long long total = (long long)N * (H + 1) * (W + 1);
   const long long blocks = (total + 255) / 256;
-  P2I_LAUNCH(metrics_fss_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, (hipStream_t)stream, bits, N, H, W,
-                     a, num, den);
+  const int nb = (int)(blocks > 8192 ? 8192 : blocks);
+  const int nv = nt * ns;
+  const DetWs ws = nv > 0 ? det_take((size_t)nb * 2 * nv, 0) : DetWs{nullptr, nullptr};
+  P2I_LAUNCH(metrics_fss_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, bits, N, H, W, a, num, den, ws);
+  if (ws.part) return det_reduce(ws.part, 2 * nv, nb, 1, 2 * nv, DetSegs{{num, den, nullptr, nullptr}, {nv, nv, 0, 0}}, (hipStream_t)stream);
   return launch_status();
 }

@@ -28,6 +28,8 @@ def _prep(preds, target):
         raise RuntimeError(f"metrics: preds {tuple(preds.shape)} and target {tuple(target.shape)} must match (..., H, W)")
     if not preds.is_cuda:
         raise RuntimeError("metrics run on the HIP path (no CPU fallback)")
+    from .. import ops
+    ops.det_ready(preds.device)          # fixed-order sums (run-to-run reproducible MAE / RMSE / FSS): include/p2i_hip.h, p2i_det_workspace
     return preds.detach().float().contiguous(), target.detach().float().contiguous()
 
 
