@@ -248,17 +248,20 @@ class TrainEngine:
             # D's REAL pass needs nothing of the generator either: its forward and backward follow on the side stream and share the
             # chip with the generator's convolutions (fill their tails); the main stream joins before D's fake pass.
             side = net_fns._side_of(G, frames.device) if (self.prep_overlap and frames.is_cuda) else None
-            gprep, dprep_f, real_out, ready = None, None, None, None
-            if side is not None:
+            real_box = [None]
+            step_start = ops.mark_stream() if side is not None else None      # the side work depends on the state at the step's start only
+
+            def enqueue_side_work():
+                # (called by generator_forward right after the attention block and the IDW are enqueued on the main stream: the
+                # GPU is already busy with the step's head while the host issues these ~100 launches)
                 b_, t_, c_, h_, w_ = masked.shape
-                gprep = side.run(lambda: net_fns.generator_prepare(G, b_, h_, w_))
+                gprep = side.run(lambda: net_fns.generator_prepare(G, b_, h_, w_), after=step_start)
                 ready = side.mark()                   # the main stream waits for the prepared weights, not for the rest of the side work
                 if self.use_gan:
                     if not D.training:
                         D.train()
-                    dprep_f = side.run(lambda: net_fns.discriminator_prepare(D, tuple(masked.shape), frames.device, False, True, pool=True))
-                    dprep_r = side.run(lambda: net_fns.discriminator_prepare(D, tuple(frames.shape), frames.device, False, True, pool=True))
-
+                    dprep_f = side.run(lambda: net_fns.discriminator_prepare(D, tuple(masked.shape), frames.device, False, True, pool=True), after=step_start)
+                    dprep_r = side.run(lambda: net_fns.discriminator_prepare(D, tuple(frames.shape), frames.device, False, True, pool=True), after=step_start)
 
                     def real_pass():
                         # forward AND backward of the real half of the D loss: every GAN loss here is a sum of a real and a fake
@@ -273,8 +276,11 @@ class TrainEngine:
                         net_fns.discriminator_backward(D, cr2, dlr2, need_x=False, inplace=True, accumulate=False)
                         return lr2, None
 
-                    real_out = side.run(real_pass, frames)
-            preds, S = net_fns.generator_forward(G, masked, masks, need_grad=True, prep=gprep, weights_ready=ready)
+                    real_box[0] = (dprep_f, side.run(real_pass, frames, after=step_start))
+                return gprep, ready
+
+            preds, S = net_fns.generator_forward(G, masked, masks, need_grad=True, after_head=enqueue_side_work if side is not None else None)
+            dprep_f, real_out = real_box[0] if real_box[0] is not None else (None, None)
             if side is not None and self.use_gan:
                 # the reconstruction loss (three short latency-bound kernels) is needed at the generator's backward only: it queues
                 # behind D's real half on the side stream while D's fake forward starts on the main stream right away

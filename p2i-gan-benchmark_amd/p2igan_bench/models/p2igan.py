@@ -237,11 +237,13 @@ def generator_prepare(net: "P2IGenerator", b: int, h: int, w: int):
     return prep
 
 
-def generator_forward(net: "P2IGenerator", masked_frames, masks, need_grad: bool, prep=None, weights_ready=None):
+def generator_forward(net: "P2IGenerator", masked_frames, masks, need_grad: bool, prep=None, weights_ready=None, after_head=None):
     """P2IGenerator.forward (p2igan.py:72-112) as a plain function: returns (frames (B,T,1,H,W), saved state or None).
     Sequences the kernels of p2igan_bench.ops; no autograd involved (TrainEngine calls this directly, _GeneratorFn wraps it).
     prep: generator_prepare's result (training only); weights_ready(): called once, right before the first kernel that reads a
-    prepared weight (TrainEngine: joins the side stream the preparation runs on)."""
+    prepared weight (TrainEngine: joins the side stream the preparation runs on).  after_head(): called right after the attention
+    block and the IDW are enqueued -- latency-bound kernels that need no weights -- and may RETURN the prep dict: TrainEngine enqueues
+    its side-stream work there, so that the GPU starts on the step's head before the host has issued the ~100 side-stream launches."""
     b, t, c, h, w = masked_frames.shape
     BASE_CH = net.base
     if c != 1 or t != net.length:
@@ -261,6 +263,10 @@ def generator_forward(net: "P2IGenerator", masked_frames, masks, need_grad: bool
     a = ops.attn_fwd(x0, att[0].weight, att[0].bias, att[1].weight, att[1].bias)
     idw, sel = ops.idw_fwd(a, mk, tau=0.05, save=need_grad)
     del a
+    if after_head is not None:
+        late = after_head()
+        if late is not None:
+            prep, weights_ready = late
     if weights_ready is not None:
         weights_ready()
     cin = _doconv_of(net.Convsin[0])

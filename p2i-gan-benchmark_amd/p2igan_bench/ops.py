@@ -256,9 +256,14 @@ class SideStream:
         self.keep = []
         self.pending = False
 
-    def run(self, fn, *tensors):
-        # everything enqueued on the forking stream so far (producers of `tensors`) -> this side stream
-        fork(_stream(), self.stream.cuda_stream)
+    def run(self, fn, *tensors, after=None):
+        # everything enqueued on the forking stream so far (producers of `tensors`) -> this side stream.  after: a token of
+        # mark_stream() instead -- the side work then depends on what the forking stream held at THAT point only (TrainEngine enqueues
+        # the step's head on the main stream first and lets the side work start beside it, not behind it)
+        if after is None:
+            fork(_stream(), self.stream.cuda_stream)
+        else:
+            _hip.check(_hip.load().p2i_event_wait(after, self.stream.cuda_stream), "p2i_event_wait")
         global _CUR_STREAM, _SIDE_DEPTH
         prev, _CUR_STREAM = _CUR_STREAM, self.stream.cuda_stream
         _SIDE_DEPTH += 1
@@ -296,6 +301,13 @@ def _next_slot() -> int:
     global _SLOT
     _SLOT = (_SLOT + 1) % 256
     return _SLOT
+
+
+def mark_stream() -> int:
+    """A token for "everything enqueued on the current launch stream so far" (SideStream.run(..., after=token))."""
+    slot = _next_slot()
+    _hip.check(_hip.load().p2i_event_record(slot, _stream()), "p2i_event_record")
+    return slot
 
 
 def fork(src_stream: int, dst_stream: int):
