@@ -672,6 +672,9 @@ extern "C" int p2i_wgrad_last_plan(int* out4) {
 static int launch_wgrad_reduce(const float* ws, int ns, long long slice, int Co, int CoPad, float* dwp, hipStream_t s, float* dbias = nullptr,
                                long long pstride = 0) {
   if (pstride == 0) pstride = slice;
+#ifdef P2I_STAMP
+  { const char* e = getenv("P2I_DEBUG_SKIP_REDUCE"); if (e && atoi(e)) return P2I_OK; }      // diagnostic build only: what the slice reduces cost a step (wrong gradients)
+#endif
   const int nmain4 = (int)(slice / 4);
   const int n4 = nmain4 + (dbias ? CoPad / 4 : 0);
   // enough threads to stream the ns * slice floats at HBM rate: split the slices over up to 8 groups while the

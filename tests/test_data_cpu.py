@@ -136,3 +136,23 @@ def test_eval_sharding_sees_every_sample_once():
         assert sorted(seen) == list(range(n))
         tr = [list(ShardedSampler(n, r, world, shuffle=True, seed=3)) for r in range(world)]
         assert len({len(t) for t in tr}) == 1 and len(set(sum(tr, []))) == sum(map(len, tr))     # training shards: equal, disjoint
+
+
+def test_zarr_chunk_cache_is_one_bounded_lru_per_process(tmp_path, monkeypatch):
+    """zarr_lite keeps decoded chunks in ONE least-recently-used cache per process, shared by every Array (round 3 kept up to 64 MB
+    per array and a dataset keeps every opened event's Array: host memory grew with events x workers)."""
+    import numpy as np
+    from p2igan_bench.data import zarr_lite
+    g = zarr_lite.Group(str(tmp_path / "s.zarr"), mode="w")
+    arrs = [g.create_dataset(f"a{i}", np.full((4, 64, 64), i, dtype=np.float32), chunks=(1, 64, 64)) for i in range(6)]     # 16 KB chunks
+    zarr_lite.Array.cache_clear()
+    monkeypatch.setattr(zarr_lite.Array, "CACHE_BYTES", 5 * 16384)
+    for a in arrs:
+        for t in range(4):
+            assert float(a[t, 0, 0]) == float(arrs.index(a))
+    assert zarr_lite.Array._lru_bytes <= 5 * 16384 and len(zarr_lite.Array._lru) == 5
+    keys = list(zarr_lite.Array._lru)
+    assert all(k[0].endswith("a5") or k[0].endswith("a4") for k in keys)            # the most recently read chunks survive
+    _ = arrs[4][3, 0, 0]                                                            # a hit moves the chunk to the young end
+    assert list(zarr_lite.Array._lru)[-1][0].endswith("a4")
+    zarr_lite.Array.cache_clear()
