@@ -203,15 +203,16 @@ def test_full_size_train_step_256_matches_reference_golden(dev, golden, engines)
     _hip_full_step(dev, golden, "e2e_256.npz", 256)
 
 
-def test_long_window_t32_matches_oracle(dev):
-    """BASELINE configs[4] (T=32).  NO REFERENCE BEHAVIOUR EXISTS for T != 16 (layer.py:310, p2igan.py:46,66,79 raise):
+@pytest.mark.parametrize("T,h,w", [(32, 32, 32), (8, 32, 32), (16, 32, 48), (16, 40, 24)], ids=["T32", "T8", "T16_32x48", "T16_40x24"])
+def test_long_window_t32_matches_oracle(dev, T, h, w):
+    """BASELINE configs[4] (T=32), the third window length the AttentionBlock kernels exist for (T=8), and non-square frames at T=16
+    (the reference's own geometry in both dimensions' roles: one full train step against the oracle, incl. the IDW tap).  NO REFERENCE BEHAVIOUR EXISTS for T != 16 (layer.py:310, p2igan.py:46,66,79 raise):
     parity UNPINNED -- this checks the HIP path against the oracle's restatement of the same generalisation (SURVEY.md H5:
     AttentionBlock(T), Convsin T->4T, base_channel 4T, discriminator in_channels T) for one full train step at 32x32."""
     from oracle import p2i_oracle as orc
     from p2igan_bench.engine import TrainEngine
     from p2igan_bench.models import build_discriminator, build_generator
     from p2igan_bench.utils import seeded
-    T, h, w = 32, 32, 32
     cfg = dict(CFG32, data={"train": {"h": h, "w": w, "sample_length": T}})
     gs, ds = seeded.seeded_generator_state(h, w, t=T), seeded.seeded_discriminator_state(t=T)
     G, D = build_generator(cfg).to(dev), build_discriminator(cfg).to(dev)
@@ -241,8 +242,12 @@ def test_long_window_t32_matches_oracle(dev):
     for n, gr in ref["dgrads"].items():
         if gr is not None:
             assert abs(float(dparams[n].grad.norm()) - float(gr.norm())) <= 1e-3 * float(gr.norm()) + 1e-7, n
+    # (the generator's gradients pass through the discriminator AFTER its Adam step -- beta1 = 0: a sign update, a gradient whose sign
+    # flips under summation-order noise moves a weight by 2e-4 -- hence the documented 2e-3 of fullsize.check for the added shapes;
+    # the first two cases keep the 1e-3 they were written with)
+    gtol = 1e-3 if (h, w) == (32, 32) else 2e-3
     for n in ("Convsin.0.main.0.W", "Convsin.0.main.0.D", "ConvsOut.0.main.0.W", "input.layers.0.conv.weight"):
-        assert rel_err(gparams[n].grad.cpu().numpy(), ref["ggrads"][n].numpy()) < 1e-3, n
+        assert rel_err(gparams[n].grad.cpu().numpy(), ref["ggrads"][n].numpy()) < gtol, n
 
 
 def test_reference_api_gan_loss_matches_oracle(dev):
