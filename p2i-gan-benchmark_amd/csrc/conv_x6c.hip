@@ -144,6 +144,7 @@ struct X6cGeom {
   // 16-byte units; plane p starts plane_units units behind plane p - 1
   const u32x4c* splanes;
   unsigned plane_units;
+  int cons_prio;        // x6p: the consumer waves raise their issue priority for the tap loop (s_setprio; P2I_X6P_PRIO, A/B)
 };
 
 // FUSED (data gradient of a stride-(.,2,2) 3x3 convolution: conv_fused.hip on the bf16 matrix pipe): the nine taps of a chunk belong
@@ -1129,6 +1130,11 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                                         // stage 0 handed over by the producers
+    // the consumers' instruction stream is operand reads + MFMAs only; the producers on the same SIMDs run VALU bursts (split pass) and
+    // vector-memory issue: with a raised priority the arbiter prefers the consumer whenever both have an instruction ready
+    if (g.cons_prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (g.cons_prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (g.cons_prio == 3) __builtin_amdgcn_s_setprio(3);
     load_tap(wlane, planes, 0, 0);
     int s = 0;
     for (int c = 0; c < nch; ++c) {
@@ -1163,6 +1169,7 @@ __global__ __launch_bounds__(64 * (4 + NPW)) void patch_gemm_x6p_kernel(const X6
       }
     }
   }
+  if (!producer && g.cons_prio) __builtin_amdgcn_s_setprio(0);
   // ---- epilogue, shared: the consumer keeps its first position block and parks the second one in LDS (every LDS image is dead
   // now: all operand reads returned before the last stage barrier), its producer partner (same SIMD) picks it up, so that all
   // eight waves load residual / mask values and store, as in the symmetric kernel
@@ -1459,6 +1466,7 @@ int run_patch_gemm_x6c(PatchGeom g, const ClassSpec& cs, const uint16_t* wb, int
   for (int i = 0; i < 9; ++i) { k.tap_off[i] = g.tap_off[i]; k.tap_w[i] = g.tap_w[i]; }
   k.sT = g.sT; k.nT = g.nT; k.mT = g.mT; k.oT = g.oT; k.pT = g.pT; k.ns = ns;
   k.stagger = x6c_stagger();
+  { const char* e = getenv("P2I_X6P_PRIO"); k.cons_prio = e ? atoi(e) : 0; }      // read per call (A/B runs)
   const int pc = x6c_pc();
   k.splanes = nullptr; k.plane_units = 0;
   if (g_next_splanes != nullptr) {                        // pre-split source (32-channel tiles with whole-chunk stages only)
@@ -1566,6 +1574,7 @@ int run_patch_gemm_x6c_fused(PatchGeom g, const ClassSpec* css, int ncls, const 
   k.nth = ceil_div(c0.nH, jh); k.ntw = ceil_div(c0.nW, jw);
   k.mg_ew = magic_u16(k.eW); k.mg_eh = magic_u16(k.eH);
   k.ntaps_w = ntaps_w; k.ksplit = ksplit; k.fused_atomic = ksplit > 1 ? 1 : 0; k.stagger = x6c_stagger();
+  { const char* e = getenv("P2I_X6P_PRIO"); k.cons_prio = e ? atoi(e) : 0; }
   k.sT = g.sT; k.nT = c0.nT; k.mT = 1; k.oT = c0.oT; k.pT = c0.pT; k.ns = ns;
   k.sdt0 = sdt[0]; k.sdt1 = sdt[1]; k.sdt2 = sdt[2]; k.swt0 = swt[0]; k.swt1 = swt[1]; k.swt2 = swt[2];
   for (int sl = 0; sl < 9; ++sl) {
